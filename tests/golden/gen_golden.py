@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE's own hot-path Python (CPU fallback path)
+on seeded synthetic inputs and writes small fixtures next to this script.
+
+Run in the build container only (needs /root/reference):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [--skip-f8]
+
+Fixtures are data: inputs (or the seed that regenerates them through
+racformer_amd.synthetic) and the reference's outputs.  Nothing of the reference's source
+is written out.  What each file pins:
+
+  geom_small.npz       decode_bbox / theta_d2xy_coods / xy2theta_d_coods / make_sample_points /
+                       inverse_sigmoid / rotation_3d_in_axis        (models/bbox/utils.py:66-106, ...)
+  msmv_small.npz       msmv_sampling (torch fallback = reference CPU path, wrapper.py:15-39), 4 levels,
+                       plus 2- and 5-level variants, stress locations outside [0,1]
+  sampling4d_small.npz sampling_4d (sparsebev_sampling.py:28-134) incl. slot-order quirk Q1
+  msda_small.npz       multi_scale_deformable_attn_pytorch (mmcv 1.6.0 semantics, stubbed on
+                       F.grid_sample in ref_loader.py; the compiled mmcv kernel is not in the tree)
+  decoder_small*.npz   full RaCFormerTransformer forward at reduced shapes + layer-0 stage outputs
+  decoder_f8*.npz      full f8 shapes: cls/box outputs of all 6 layers + stage checksums
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import ref_loader  # noqa: E402
+from racformer_amd import synthetic as syn  # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def gen_geom(ref):
+    bu, mu, sp = ref.utils_bbox, ref.utils, ref.sparsebev_sampling
+    rng = np.random.default_rng(7)
+    q = torch.from_numpy(rng.standard_normal((2, 9, 10), dtype=np.float32))
+    q[..., 0:3] = torch.from_numpy(rng.random((2, 9, 3), dtype=np.float32))
+    q[0, 0, 0:2] = torch.tensor([0.0, 1.0])     # clamp edge: d=1 -> 65 m > 51.2 m
+    q[0, 1, 0:2] = torch.tensor([0.999, 0.0])
+    off = torch.from_numpy(rng.standard_normal((2, 9, 5, 3), dtype=np.float32))
+    xy = torch.from_numpy(rng.random((2, 9, 7, 3), dtype=np.float32))
+    xy[0, 0, 0, :2] = 0.5                          # atan2(0,0)
+    x = torch.tensor([-0.5, 0.0, 1e-7, 0.3, 0.5, 1 - 1e-7, 1.0, 1.5])
+    save("geom_small.npz",
+         q=q, off=off, xy=xy, x=x,
+         decode_bbox=bu.decode_bbox(q, syn.PC_RANGE),
+         theta_d2xy=bu.theta_d2xy_coods(q),
+         xy2theta_d=bu.xy2theta_d_coods(xy),
+         denormalize_bbox=bu.denormalize_bbox(q),
+         make_sample_points=sp.make_sample_points(bu.theta_d2xy_coods(q).clone(), off, syn.PC_RANGE),
+         inverse_sigmoid=mu.inverse_sigmoid(x),
+         rotation=mu.rotation_3d_in_axis(off, q[..., 6:7]))
+
+
+def _stress_loc(rng, S, Q, P, N):
+    loc = rng.random((S, Q, P, 3), dtype=np.float32) * 1.1 - 0.05
+    view = rng.integers(0, N, size=(S, Q, P))
+    loc[..., 2] = view.astype(np.float32) / np.float32(max(N - 1, 1))
+    # exact-edge and far-outside cases
+    loc[0, 0, 0, :2] = (0.0, 0.0)
+    loc[0, 0, 1, :2] = (1.0, 1.0)
+    loc[0, 0, 2, :2] = (-1e5, 0.5)
+    loc[0, 0, 3, :2] = (0.5, 1e5)
+    loc[0, 1, 0, :2] = (1.0 + 1e-3, 0.5)
+    loc[0, 1, 1, :2] = (-1e-3, 0.5)
+    return loc
+
+
+def gen_msmv(ref):
+    wr = ref.wrapper
+    rng = np.random.default_rng(11)
+    S, N, C, Q, P = 4, 3, 8, 7, 6
+    all_hw = [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)]
+    out = {}
+    for tag, hws in (("c2345", all_hw[:4]), ("c45", all_hw[2:4]), ("c23456", all_hw)):
+        L = len(hws)
+        feats_cl = [rng.standard_normal((S, N, h, w, C), dtype=np.float32) for h, w in hws]
+        loc = _stress_loc(rng, S, Q, P, N)
+        w_ = rng.standard_normal((S, Q, P, L), dtype=np.float32)
+        w_ = np.exp(w_) / np.exp(w_).sum(-1, keepdims=True)
+        feats_cf = [torch.from_numpy(f).permute(0, 4, 1, 2, 3).contiguous() for f in feats_cl]
+        res = wr.msmv_sampling_pytorch(feats_cf, torch.from_numpy(loc), torch.from_numpy(w_))
+        for i, f in enumerate(feats_cl):
+            out[f"{tag}_feat{i}"] = f
+        out[f"{tag}_loc"] = loc
+        out[f"{tag}_w"] = w_.astype(np.float32)
+        out[f"{tag}_out"] = res.contiguous()
+    save("msmv_small.npz", **out)
+
+
+def gen_sampling4d(ref):
+    sp = ref.sparsebev_sampling
+    rng = np.random.default_rng(13)
+    B, Q, T, G, P, N, L, C = 1, 7, 3, 4, 5, 6, 4, 4
+    hws = [(16, 44), (8, 22), (4, 11), (2, 6)]
+    H, W = 64, 176
+    feats_cl = [rng.standard_normal((B * T * G, N, h, w, C), dtype=np.float32) for h, w in hws]
+    feats_cf = [torch.from_numpy(f).permute(0, 4, 1, 2, 3).contiguous() for f in feats_cl]
+    pts = rng.standard_normal((B, Q, T, G, P, 3), dtype=np.float32) * np.float32(15.0)
+    pts[..., 2] = pts[..., 2] * 0.1 + 1.0
+    sw = rng.standard_normal((B, Q, G, T, P, L), dtype=np.float32)
+    sw = np.exp(sw) / np.exp(sw).sum(-1, keepdims=True)
+    l2i = np.asarray(syn.ring_lidar2img(T, N, (H, W))).astype(np.float32)[None]
+    out = sp.sampling_4d(torch.from_numpy(pts), feats_cf, torch.from_numpy(sw.astype(np.float32)),
+                         torch.from_numpy(l2i), H, W)
+    d = {f"feat{i}": f for i, f in enumerate(feats_cl)}
+    save("sampling4d_small.npz", pts=pts, scale_weights=sw.astype(np.float32), lidar2img=l2i,
+         image_hw=np.array([H, W]), out=out, **d)
+
+
+def gen_msda():
+    rng = np.random.default_rng(17)
+    bs, Hh, Ww, heads, D, Q, P = 3, 9, 13, 4, 8, 11, 5
+    value = rng.standard_normal((bs, Hh * Ww, heads, D), dtype=np.float32)
+    loc = rng.random((bs, Q, heads, 1, P, 2), dtype=np.float32) * 1.2 - 0.1
+    loc[0, 0, 0, 0, 0] = (0.0, 0.0)
+    loc[0, 0, 0, 0, 1] = (1.0, 1.0)
+    loc[0, 0, 0, 0, 2] = (0.5 / Ww, 0.5 / Hh)
+    attn = rng.random((bs, Q, heads, 1, P), dtype=np.float32)
+    attn /= attn.sum(-1, keepdims=True)
+    shapes = torch.tensor([[Hh, Ww]], dtype=torch.long)
+    out = ref_loader._msda_pytorch(torch.from_numpy(value), shapes, torch.from_numpy(loc),
+                                   torch.from_numpy(attn))
+    # two-level case
+    hw2 = [(6, 8), (3, 4)]
+    keys = sum(h * w for h, w in hw2)
+    value2 = rng.standard_normal((2, keys, 2, 16), dtype=np.float32)
+    loc2 = rng.random((2, 5, 2, 2, 3, 2), dtype=np.float32) * 1.2 - 0.1
+    attn2 = rng.random((2, 5, 2, 2, 3), dtype=np.float32)
+    out2 = ref_loader._msda_pytorch(torch.from_numpy(value2), torch.tensor(hw2), torch.from_numpy(loc2),
+                                    torch.from_numpy(attn2))
+    save("msda_small.npz", value=value, loc=loc, attn=attn, shapes=shapes.numpy(), out=out,
+         value2=value2, loc2=loc2, attn2=attn2, shapes2=np.array(hw2), out2=out2)
+
+
+STAGES = ["position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_bev", "sampling",
+          "mixing", "ffn"]
+
+
+def run_decoder(ref, cfg, seed, weight_seed, full_stages):
+    tr = ref.racformer_transformer.RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+    syn.fill_params(tr, weight_seed)
+    layer = tr.decoder.decoder_layer
+    captured = {}
+
+    def mk(name):
+        def hook(mod, inp, out):
+            captured.setdefault(name, []).append(out.detach().clone())
+        return hook
+
+    hs = [getattr(layer, s).register_forward_hook(mk(s)) for s in STAGES]
+    hs.append(layer.sampling_radar_bev.temporal_encoder.register_forward_hook(mk("temporal_encoder")))
+    qb, qf = syn.make_queries(cfg, seed)
+    feats = syn.make_pyramid(cfg, seed)
+    lss, radar = syn.make_bev(cfg, seed, 0), syn.make_bev(cfg, seed, 1)
+    metas = syn.make_img_metas(cfg)
+    t0 = time.time()
+    with torch.no_grad():
+        cls, box = tr(qb, qf, feats, lss, radar, None, metas)
+    dt = time.time() - t0
+    for h in hs:
+        h.remove()
+    out = dict(cls=cls, box=box, seed=np.array(seed), weight_seed=np.array(weight_seed),
+               ref_cpu_seconds=np.array(dt), time_diff=metas[0]["time_diff"])
+    for s, lst in captured.items():
+        for li in (0, len(lst) - 1):
+            t = lst[li]
+            key = f"{s}_L{li}"
+            if s == "temporal_encoder":
+                # big map: keep a strided probe + moments
+                out[key + "_probe"] = t[:, :, ::37, ::9, ::11].contiguous()
+                out[key + "_mean_std"] = np.array([t.mean().item(), t.std().item()])
+            elif full_stages:
+                out[key] = t
+            else:
+                out[key + "_head"] = t[:, :16].contiguous()
+                out[key + "_mean_std"] = np.array([t.double().mean().item(), t.double().std().item()])
+    return out, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-f8", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    ref = ref_loader.load_reference()
+    ref.utils_bbox = sys.modules["models.bbox.utils"]
+    ref.utils = sys.modules["models.utils"]
+
+    def want(k):
+        return not args.only or k in args.only.split(",")
+
+    if want("geom"):
+        gen_geom(ref)
+    if want("msmv"):
+        gen_msmv(ref)
+    if want("s4d"):
+        gen_sampling4d(ref)
+    if want("msda"):
+        gen_msda()
+    if want("small"):
+        out, dt = run_decoder(ref, syn.SMALL, seed=1, weight_seed=3, full_stages=True)
+        print(f"  decoder SMALL ref forward {dt:.2f}s")
+        save("decoder_small.npz", **out)
+        out, dt = run_decoder(ref, syn.SMALL6, seed=2, weight_seed=4, full_stages=True)
+        save("decoder_small6.npz", **out)
+    if not args.skip_f8 and want("f8"):
+        out, dt = run_decoder(ref, syn.F8, seed=0, weight_seed=0, full_stages=False)
+        print(f"  decoder F8 ref forward {dt:.2f}s")
+        save("decoder_f8.npz", **out)
+    if not args.skip_f8 and want("f8_3cam"):
+        out, dt = run_decoder(ref, syn.F8_3CAM, seed=0, weight_seed=0, full_stages=False)
+        print(f"  decoder F8 3-cam ref forward {dt:.2f}s")
+        save("decoder_f8_3cam.npz", **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""Pins the CPU oracle (oracle/restate.py + oracle/gather_ref.c) against golden vectors produced
+by the reference's own CPU path (tests/golden/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restate as R
+from racformer_amd import synthetic as syn
+from parity import decoder_parity
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def assert_close(a, b, atol, rtol=0.0, what=""):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    lim = atol + rtol * b.abs()
+    assert bool((err <= lim).all()), f"{what}: max err {err.max().item():.3e} (atol {atol}, rtol {rtol})"
+
+
+def test_geometry(golden_dir):
+    g = load(golden_dir, "geom_small.npz")
+    q, off, xy, x = t(g["q"]), t(g["off"]), t(g["xy"]), t(g["x"])
+    assert_close(R.decode_bbox(q, syn.PC_RANGE), g["decode_bbox"], 1e-6, 1e-6, "decode_bbox")
+    assert_close(R.theta_d2xy(q), g["theta_d2xy"], 1e-6, 0, "theta_d2xy")
+    assert_close(R.xy2theta_d(xy), g["xy2theta_d"], 1e-6, 0, "xy2theta_d")
+    assert_close(R.denormalize_bbox(q), g["denormalize_bbox"], 1e-6, 1e-6, "denormalize")
+    assert_close(R.make_sample_points(R.theta_d2xy(q), off, syn.PC_RANGE), g["make_sample_points"],
+                 1e-5, 1e-6, "make_sample_points")
+    assert_close(R.inverse_sigmoid(x), g["inverse_sigmoid"], 1e-6, 0, "inverse_sigmoid")
+    assert_close(R.rotate_z(off, q[..., 6:7]), g["rotation"], 1e-6, 0, "rotation")
+
+
+@pytest.mark.parametrize("tag,L", [("c2345", 4), ("c45", 2), ("c23456", 5)])
+@pytest.mark.parametrize("force_torch", [False, True])
+def test_msmv(golden_dir, tag, L, force_torch):
+    g = load(golden_dir, "msmv_small.npz")
+    feats = [t(g[f"{tag}_feat{i}"]) for i in range(L)]
+    out = R.msmv_gather(feats, t(g[f"{tag}_loc"]), t(g[f"{tag}_w"]), force_torch=force_torch)
+    # reference fallback interpolates the view axis trilinearly (weight ~1e-7 on the neighbour
+    # view): equal within fp32 noise, not bit-identical.
+    assert_close(out, g[f"{tag}_out"], 2e-5, 0, f"msmv {tag}")
+
+
+def test_msmv_c_equals_torch(golden_dir):
+    if R._clib() is None:
+        pytest.skip("C oracle not built")
+    g = load(golden_dir, "msmv_small.npz")
+    feats = [t(g[f"c2345_feat{i}"]) for i in range(4)]
+    a = R.msmv_gather(feats, t(g["c2345_loc"]), t(g["c2345_w"]))
+    b = R.msmv_gather(feats, t(g["c2345_loc"]), t(g["c2345_w"]), force_torch=True)
+    assert_close(a, b, 1e-6, 0, "C vs torch msmv")
+
+
+def test_sampling_4d_slot_quirk(golden_dir):
+    g = load(golden_dir, "sampling4d_small.npz")
+    feats = [t(g[f"feat{i}"]) for i in range(4)]
+    H, W = [int(v) for v in g["image_hw"]]
+    out = R.sampling_4d(t(g["pts"]), feats, t(g["scale_weights"]), t(g["lidar2img"]), H, W)
+    assert_close(out, g["out"], 3e-5, 0, "sampling_4d")
+
+
+@pytest.mark.parametrize("force_torch", [False, True])
+def test_msda(golden_dir, force_torch):
+    g = load(golden_dir, "msda_small.npz")
+    out = R.msda(t(g["value"]), g["shapes"].tolist(), [0], t(g["loc"]), t(g["attn"]),
+                 force_torch=force_torch)
+    assert_close(out, g["out"], 1e-5, 0, "msda L=1")
+    hw2 = g["shapes2"].tolist()
+    out2 = R.msda(t(g["value2"]), hw2, [0, hw2[0][0] * hw2[0][1]], t(g["loc2"]), t(g["attn2"]),
+                  force_torch=force_torch)
+    assert_close(out2, g["out2"], 1e-5, 0, "msda L=2")
+
+
+def _run_decoder(cfg, g, stages=None):
+    seed, wseed = int(g["seed"]), int(g["weight_seed"])
+    sd = syn.make_state_dict(cfg, wseed)
+    qb, qf = syn.make_queries(cfg, seed)
+    with torch.no_grad():
+        return R.transformer_forward(sd, qb, qf, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
+                                     syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg, stages)
+
+
+@pytest.mark.parametrize("name,cfg", [("decoder_small.npz", syn.SMALL), ("decoder_small6.npz", syn.SMALL6)])
+def test_decoder_small(golden_dir, name, cfg):
+    g = load(golden_dir, name)
+    stages = []
+    cls, box = _run_decoder(cfg, g, stages)
+    for li, tol in ((0, 1e-4), (cfg.num_layers - 1, 1e-3)):
+        for s in ("position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_bev", "sampling",
+                  "mixing", "ffn"):
+            assert_close(stages[li][s], g[f"{s}_L{li}"], tol, tol, f"{s} L{li}")
+    decoder_parity(cls, box, g["cls"], g["box"], what=name)
+
+
+@pytest.mark.parametrize("name,cfg", [("decoder_f8.npz", syn.F8), ("decoder_f8_3cam.npz", syn.F8_3CAM)])
+def test_decoder_f8(golden_dir, name, cfg):
+    """Full f8 shapes (about 15 s of CPU each): north_star tolerance -- box regressions within
+    1e-3, class argmax bit-exact -- for the oracle against the reference CPU forward."""
+    g = load(golden_dir, name)
+    torch.set_num_threads(os.cpu_count())
+    cls, box = _run_decoder(cfg, g)
+    decoder_parity(cls, box, g["cls"], g["box"], what=name)

@@ -1,0 +1,99 @@
+"""ctypes binding of libracformer_hip.so (C-ABI in include/racformer_hip.h).
+
+No fallback: if the library is missing, or a call fails, this raises.  Tensors are plumbing
+(device memory + the current HIP stream); the kernels themselves are hand-written HIP.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libracformer_hip.so")
+RAC_F32, RAC_BF16 = 0, 1
+OUT_SQCP, OUT_BQGTPC = 0, 1
+_lib = None
+
+# name -> (restype, argtypes); must list every symbol include/racformer_hip.h declares
+_vp, _i = ctypes.c_void_p, ctypes.c_int
+SIGNATURES = {
+    "rac_abi_version": (_i, []),
+    "rac_last_error": (ctypes.c_char_p, []),
+    "rac_msmv_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rac_msda_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rac_regroup_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+}
+
+
+def lib():
+    """The loaded C-ABI library.  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"racformer_amd: HIP library not built ({LIB_PATH}); run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C racformer_amd/csrc`. "
+                "There is no CPU fallback for the hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().rac_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return RAC_F32
+    if t.dtype == torch.bfloat16:
+        return RAC_BF16
+    raise TypeError(f"racformer_amd: unsupported feature dtype {t.dtype} (float32 or bfloat16)")
+
+
+def require_gpu(*tensors, what="op"):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(f"racformer_amd.{what}: tensor must be a CUDA tensor "
+                               "(HIP device); the hot path has no CPU fallback")
+        if not t.is_contiguous():
+            raise RuntimeError(f"racformer_amd.{what}: tensor has to be contiguous")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ---- optional per-kernel timing hook (bench.py): events recorded on the launch stream ---------
+class KernelTimer:
+    """Brackets selected launches with HIP events on torch's current stream (the stream the
+    C-ABI launches on) and reports the mean elapsed time per launch after a synchronise."""
+
+    def __init__(self):
+        self.events = {}
+
+    def record(self, name):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(name, []).append((start, end))
+        return start, end
+
+    def mean_ms(self, name):
+        ev = self.events.get(name, [])
+        if not ev:
+            return None
+        return sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+
+    def reset(self):
+        self.events = {}
+
+
+timer = None  # set to a KernelTimer by bench.py for the timed region

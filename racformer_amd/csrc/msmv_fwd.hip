@@ -1,0 +1,262 @@
+// msmv_fwd.hip -- multi-scale multi-view sampling, forward, for gfx950 (MI355X).
+//
+// Replaces the reference's ms_deformable_im2col_gpu_kernel_{c45,c2345,c23456}
+// (models/csrc/msmv_sampling/msmv_sampling_forward.cu:75-334) behind rac_msmv_fwd.
+// Semantics (same as the reference kernel, :105-157 and :27-73): per point, view =
+// round(loc_v*(N-1)); per level h_im = v*(H-1), w_im = u*(W-1) (align_corners=True), level
+// skipped unless h_im>-1 && w_im>-1 && h_im<H && w_im<W; 4 bilinear taps, each bounds-checked,
+// zero padding; levels accumulated in order c2..c5 with their scale weight.
+//
+// CDNA4 mapping (not the reference's thread-per-channel scheme):
+//  * C=64 fast path: a 16-lane group owns one sampling point; each lane holds 4 adjacent
+//    channels, so every tap is one 16-byte load per lane and one wave-instruction fetches four
+//    256-byte pixel rows (1 KiB).  A wave64 walks the P points of one (slot, query) row four at
+//    a time; all 4 levels x 4 taps = 16 independent loads are in flight per lane before the
+//    first FMA.  No cross-lane reduction is needed: the reduction over levels/taps is in-register.
+//  * per-row sampling locations / scale weights are staged once per workgroup through LDS
+//    (coalesced global read, broadcast LDS reads inside each 16-lane group).
+//  * block -> (slot, query block) mapping is XCD-aware: blocks b and b+8 share an XCD (and its
+//    4 MiB L2), so XCD x walks slots x, x+8, ... and the 32 CUs of one XCD work on the same
+//    slot's 23 MB pyramid at the same time, neighbouring queries (adjacent rays) together.
+//  * RAC_OUT_BQGTPC writes the consumer layout directly: each 16-lane group stores one 256-byte
+//    pixel row, 1 KiB contiguous per wave-instruction (the reference's P-minor layout needs
+//    48-byte-strided 4-byte stores and a separate 88 MB permute afterwards).
+#include "rac_common.h"
+
+struct MsmvArgs {
+    const void *feat[RAC_MAX_LEVELS];
+    int H[RAC_MAX_LEVELS];
+    int W[RAC_MAX_LEVELS];
+    const float *loc;
+    const float *w;
+    float *out;
+    int L, S, N, Q, P, C;
+    int T, G;
+    int blocks_per_slot;
+};
+
+#define MSMV_ROWS 4 /* (slot,query) rows per 256-thread workgroup: one per wave */
+
+template <typename FT>
+__device__ __forceinline__ rac_f4 msmv_tap(const FT *base, int h, int w, int W, bool ok)
+{
+    rac_f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok)
+        v = rac_ld4(base + ((size_t)h * W + w) * 64);
+    return v;
+}
+
+template <typename FT, int L, bool OUT_CL>
+__global__ __launch_bounds__(256) void msmv_fwd_c64_kernel(const MsmvArgs a)
+{
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, sub = lane >> 4, c4 = lane & 15;
+    const int P = a.P;
+
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int s = xcd + 8 * (j / a.blocks_per_slot);
+    if (s >= a.S)
+        return;
+    const int q0 = (j % a.blocks_per_slot) * MSMV_ROWS;
+    const int nrows = min(MSMV_ROWS, a.Q - q0);
+
+    float *sloc = smem;                      // [rows][P][3]
+    float *sw = smem + MSMV_ROWS * P * 3;    // [rows][P][L]
+    const size_t row0 = (size_t)s * a.Q + q0;
+    {
+        const float *gl = a.loc + row0 * P * 3;
+        const float *gw = a.w + row0 * P * L;
+        for (int i = tid; i < nrows * P * 3; i += 256)
+            sloc[i] = gl[i];
+        for (int i = tid; i < nrows * P * L; i += 256)
+            sw[i] = gw[i];
+    }
+    __syncthreads();
+    if (wave >= nrows)
+        return;
+    const int q = q0 + wave;
+
+    size_t out_row;  // element offset of this row's output block
+    if (OUT_CL) {
+        const int g = s % a.G, t = (s / a.G) % a.T, b = s / (a.G * a.T);
+        out_row = ((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * (size_t)P * 64;
+    } else {
+        out_row = ((size_t)s * a.Q + q) * 64 * (size_t)P;
+    }
+
+    for (int p0 = 0; p0 < P; p0 += 4) {
+        const int p = p0 + sub;
+        const bool act = p < P;
+        const int pp = act ? p : P - 1;
+        const float *lp = sloc + (wave * P + pp) * 3;
+        const float *wp = sw + (wave * P + pp) * L;
+        const float lu = lp[0], lv = lp[1];
+        int view = (int)roundf(lp[2] * (float)(a.N - 1));
+        view = min(max(view, 0), a.N - 1);
+
+        rac_f4 v[L][4];
+        float tw[L][4];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int H = a.H[l], W = a.W[l];
+            const float h_im = lv * (float)(H - 1);
+            const float w_im = lu * (float)(W - 1);
+            const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const FT *base = (const FT *)a.feat[l] + ((size_t)s * a.N + view) * H * W * 64 + c4 * 4;
+            const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
+            const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+            v[l][0] = msmv_tap(base, h_low, w_low, W, t_ok && l_ok);
+            v[l][1] = msmv_tap(base, h_low, w_high, W, t_ok && r_ok);
+            v[l][2] = msmv_tap(base, h_high, w_low, W, b_ok && l_ok);
+            v[l][3] = msmv_tap(base, h_high, w_high, W, b_ok && r_ok);
+            tw[l][0] = hh * hw;
+            tw[l][1] = hh * lw;
+            tw[l][2] = lh * hw;
+            tw[l][3] = lh * lw;
+        }
+        rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float wl = wp[l];
+            acc.x += (tw[l][0] * v[l][0].x + tw[l][1] * v[l][1].x + tw[l][2] * v[l][2].x + tw[l][3] * v[l][3].x) * wl;
+            acc.y += (tw[l][0] * v[l][0].y + tw[l][1] * v[l][1].y + tw[l][2] * v[l][2].y + tw[l][3] * v[l][3].y) * wl;
+            acc.z += (tw[l][0] * v[l][0].z + tw[l][1] * v[l][1].z + tw[l][2] * v[l][2].z + tw[l][3] * v[l][3].z) * wl;
+            acc.w += (tw[l][0] * v[l][0].w + tw[l][1] * v[l][1].w + tw[l][2] * v[l][2].w + tw[l][3] * v[l][3].w) * wl;
+        }
+        if (act) {
+            if (OUT_CL) {
+                *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = acc;
+            } else {
+                float *o = a.out + out_row + (size_t)(c4 * 4) * P + p;
+                o[0] = acc.x;
+                o[(size_t)P] = acc.y;
+                o[(size_t)2 * P] = acc.z;
+                o[(size_t)3 * P] = acc.w;
+            }
+        }
+    }
+}
+
+// Any C / any L<=8: one thread per (row, point, channel), channel fastest (coalesced taps).
+template <typename FT>
+__device__ __forceinline__ float msmv_ld1(const FT *p);
+template <>
+__device__ __forceinline__ float msmv_ld1<float>(const float *p) { return *p; }
+template <>
+__device__ __forceinline__ float msmv_ld1<unsigned short>(const unsigned short *p) { return rac_bf16_to_f32(*p); }
+
+template <typename FT>
+__global__ __launch_bounds__(256) void msmv_fwd_generic_kernel(const MsmvArgs a)
+{
+    const long total = (long)a.S * a.Q * a.P * a.C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % a.C);
+        const long rp = idx / a.C;
+        const int p = (int)(rp % a.P);
+        const long r = rp / a.P;
+        const int s = (int)(r / a.Q), q = (int)(r % a.Q);
+        const float *lp = a.loc + rp * 3;
+        const float *wp = a.w + rp * a.L;
+        const float lu = lp[0], lv = lp[1];
+        int view = (int)roundf(lp[2] * (float)(a.N - 1));
+        view = min(max(view, 0), a.N - 1);
+        float acc = 0.f;
+        for (int l = 0; l < a.L; ++l) {
+            const int H = a.H[l], W = a.W[l];
+            const float h_im = lv * (float)(H - 1), w_im = lu * (float)(W - 1);
+            if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W))
+                continue;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const FT *base = (const FT *)a.feat[l] + ((size_t)s * a.N + view) * H * W * a.C + c;
+            float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+            if (h_low >= 0 && w_low >= 0) v1 = msmv_ld1(base + ((size_t)h_low * W + w_low) * a.C);
+            if (h_low >= 0 && w_high <= W - 1) v2 = msmv_ld1(base + ((size_t)h_low * W + w_high) * a.C);
+            if (h_high <= H - 1 && w_low >= 0) v3 = msmv_ld1(base + ((size_t)h_high * W + w_low) * a.C);
+            if (h_high <= H - 1 && w_high <= W - 1) v4 = msmv_ld1(base + ((size_t)h_high * W + w_high) * a.C);
+            acc += (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4) * wp[l];
+        }
+        size_t o;
+        if (a.T > 0) {  // RAC_OUT_BQGTPC
+            const int g = s % a.G, t = (s / a.G) % a.T, b = s / (a.G * a.T);
+            o = (((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * a.P + p) * a.C + c;
+        } else {
+            o = ((size_t)r * a.C + c) * a.P + p;
+        }
+        a.out[o] = acc;
+    }
+}
+
+template <typename FT, bool OUT_CL>
+static int launch_c64(const MsmvArgs &a, hipStream_t st)
+{
+    const int nb = 8 * ((a.S + 7) / 8) * a.blocks_per_slot;
+    const size_t lds = (size_t)MSMV_ROWS * a.P * (3 + a.L) * sizeof(float);
+    switch (a.L) {
+    case 2: hipLaunchKernelGGL((msmv_fwd_c64_kernel<FT, 2, OUT_CL>), dim3(nb), dim3(256), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((msmv_fwd_c64_kernel<FT, 4, OUT_CL>), dim3(nb), dim3(256), lds, st, a); break;
+    case 5: hipLaunchKernelGGL((msmv_fwd_c64_kernel<FT, 5, OUT_CL>), dim3(nb), dim3(256), lds, st, a); break;
+    default: return 1;
+    }
+    return 0;
+}
+
+extern "C" int rac_msmv_fwd(const void *const *feats, const int32_t *hw, int L, const float *loc,
+                            const float *w, float *out, int S, int N, int Q, int P, int C, int dtype,
+                            int out_layout, int T, int G, void *stream)
+{
+    RAC_CHECK_ARG(feats && hw && loc && w && out, "rac_msmv_fwd: null pointer");
+    RAC_CHECK_ARG(L >= 1 && L <= RAC_MAX_LEVELS, "rac_msmv_fwd: L=%d out of [1,%d]", L, RAC_MAX_LEVELS);
+    RAC_CHECK_ARG(S >= 0 && Q >= 0 && N >= 1 && C >= 1, "rac_msmv_fwd: bad sizes S=%d N=%d Q=%d C=%d", S, N, Q, C);
+    RAC_CHECK_ARG(P >= 0 && P <= RAC_MAX_POINTS, "rac_msmv_fwd: num_point exceed limits (P=%d > %d)", P, RAC_MAX_POINTS);
+    RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_msmv_fwd: dtype %d", dtype);
+    RAC_CHECK_ARG(out_layout == RAC_OUT_SQCP || out_layout == RAC_OUT_BQGTPC, "rac_msmv_fwd: layout %d", out_layout);
+    if (out_layout == RAC_OUT_BQGTPC)
+        RAC_CHECK_ARG(T >= 1 && G >= 1 && S % (T * G) == 0, "rac_msmv_fwd: S=%d not a multiple of T*G=%d*%d", S, T, G);
+    MsmvArgs a;
+    for (int l = 0; l < L; ++l) {
+        RAC_CHECK_ARG(feats[l] != nullptr, "rac_msmv_fwd: feats[%d] is null", l);
+        RAC_CHECK_ARG(hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "rac_msmv_fwd: level %d has empty map", l);
+        a.feat[l] = feats[l];
+        a.H[l] = hw[2 * l];
+        a.W[l] = hw[2 * l + 1];
+    }
+    for (int l = L; l < RAC_MAX_LEVELS; ++l) {
+        a.feat[l] = nullptr;
+        a.H[l] = a.W[l] = 1;
+    }
+    a.loc = loc; a.w = w; a.out = out;
+    a.L = L; a.S = S; a.N = N; a.Q = Q; a.P = P; a.C = C;
+    a.T = out_layout == RAC_OUT_BQGTPC ? T : 0;
+    a.G = out_layout == RAC_OUT_BQGTPC ? G : 1;
+    a.blocks_per_slot = (Q + MSMV_ROWS - 1) / MSMV_ROWS;
+    if (S == 0 || Q == 0 || P == 0)
+        return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int fell_through = 1;
+    if (C == 64 && (L == 2 || L == 4 || L == 5)) {
+        if (dtype == RAC_F32)
+            fell_through = out_layout == RAC_OUT_BQGTPC ? launch_c64<float, true>(a, st) : launch_c64<float, false>(a, st);
+        else
+            fell_through = out_layout == RAC_OUT_BQGTPC ? launch_c64<unsigned short, true>(a, st)
+                                                        : launch_c64<unsigned short, false>(a, st);
+    }
+    if (fell_through) {
+        const long total = (long)S * Q * P * C;
+        const int nb = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+        if (dtype == RAC_F32)
+            hipLaunchKernelGGL(msmv_fwd_generic_kernel<float>, dim3(nb), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(msmv_fwd_generic_kernel<unsigned short>, dim3(nb), dim3(256), 0, st, a);
+    }
+    return rac_launch_status("rac_msmv_fwd");
+}

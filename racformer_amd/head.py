@@ -1,0 +1,136 @@
+"""Inference-side counterparts of ``RaCFormer_head`` (models/racformer_head.py:13-134, 488-507)
+and ``NMSFreeCoder`` (models/bbox/coders/nms_free_coder.py:8-110): same names, constructor
+arguments, ``forward`` / ``get_bboxes`` / ``decode`` behaviour and ``state_dict`` keys
+(``init_query_bbox.weight``, ``label_enc.weight``, ``code_weights``, ``transformer.*``).
+Training-only parts (query denoising, losses, assigners) are out of scope."""
+import torch
+import torch.nn as nn
+
+from .bbox_utils import denormalize_bbox
+from .transformer import RaCFormerTransformer
+
+
+class NMSFreeCoder:
+    """nms_free_coder.py:8-110"""
+
+    def __init__(self, pc_range, voxel_size=None, post_center_range=None, max_num=100, score_threshold=None,
+                 num_classes=10):
+        self.pc_range, self.voxel_size, self.post_center_range = pc_range, voxel_size, post_center_range
+        self.max_num, self.score_threshold, self.num_classes = max_num, score_threshold, num_classes
+
+    def topk_fixed(self, cls_scores, bbox_preds):
+        """The shape-static half of decode_single (:48-57 + masks :61-69): no boolean indexing,
+        so nothing synchronises with the host.  -> boxes [K,9], scores [K], labels [K], keep [K]."""
+        scores, indexs = cls_scores.sigmoid().view(-1).topk(self.max_num)
+        labels = indexs % self.num_classes
+        bbox_index = torch.div(indexs, self.num_classes, rounding_mode="trunc")
+        boxes = denormalize_bbox(bbox_preds[bbox_index])
+        if self.post_center_range is None:
+            raise NotImplementedError("Need to reorganize output as a batch, only support "
+                                      "post_center_range is not None for now!")
+        limit = boxes.new_tensor(self.post_center_range)
+        keep = (boxes[..., :3] >= limit[:3]).all(1) & (boxes[..., :3] <= limit[3:]).all(1)
+        if self.score_threshold:
+            keep &= scores > self.score_threshold
+        return boxes, scores, labels, keep
+
+    def decode_single(self, cls_scores, bbox_preds):
+        boxes, scores, labels, keep = self.topk_fixed(cls_scores, bbox_preds)
+        return {"bboxes": boxes[keep], "scores": scores[keep], "labels": labels[keep]}
+
+    def decode(self, preds_dicts):
+        all_cls_scores = preds_dicts["all_cls_scores"][-1]
+        all_bbox_preds = preds_dicts["all_bbox_preds"][-1]
+        return [self.decode_single(all_cls_scores[i], all_bbox_preds[i]) for i in range(all_cls_scores.size(0))]
+
+
+class RaCFormer_head(nn.Module):
+    """Inference branch of models/racformer_head.py.  ``transformer`` is a config dict
+    (``type='RaCFormerTransformer'``, as in configs/racformer_r50_nuimg_704x256_f8.py:152-166) or a
+    module; ``bbox_coder`` a config dict (``type='NMSFreeCoder'``) or an instance."""
+
+    def __init__(self, *args, num_classes, in_channels, num_query=900, num_clusters=5, transformer=None,
+                 bbox_coder=None, code_size=10, code_weights=[1.0] * 10, query_denoising=True,
+                 query_denoising_groups=10, train_cfg=dict(), test_cfg=dict(max_per_img=100), **kwargs):
+        super().__init__()
+        self.num_classes, self.in_channels, self.embed_dims = num_classes, in_channels, in_channels
+        self.num_query, self.num_clusters, self.code_size = num_query, num_clusters, code_size
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if isinstance(transformer, dict):
+            tcfg = dict(transformer)
+            assert tcfg.pop("type", "RaCFormerTransformer") == "RaCFormerTransformer"
+            transformer = RaCFormerTransformer(**tcfg)
+        self.transformer = transformer
+        if isinstance(bbox_coder, dict):
+            ccfg = dict(bbox_coder)
+            assert ccfg.pop("type", "NMSFreeCoder") == "NMSFreeCoder"
+            bbox_coder = NMSFreeCoder(**ccfg)
+        self.bbox_coder = bbox_coder
+        self.pc_range = self.bbox_coder.pc_range
+        self.code_weights = nn.Parameter(torch.tensor(code_weights), requires_grad=False)
+        self._init_layers()
+
+    def _init_layers(self):
+        """racformer_head.py:51-63: polar query grid (num_query//num_clusters rays x clusters)."""
+        self.init_query_bbox = nn.Embedding(self.num_query, 10)
+        self.label_enc = nn.Embedding(self.num_classes + 1, self.embed_dims - 1)
+        with torch.no_grad():
+            nn.init.constant_(self.init_query_bbox.weight[:, 2:3], 0.5)
+            nn.init.zeros_(self.init_query_bbox.weight[:, 8:10])
+            nn.init.constant_(self.init_query_bbox.weight[:, 5:6], 0.2)
+            self.init_query_bbox.weight[:, :2] = self.generate_points().reshape(-1, 2)
+
+    def init_weights(self):
+        self.transformer.init_weights()
+
+    def generate_points(self):
+        """racformer_head.py:69-79"""
+        num_angles = self.num_query // self.num_clusters
+        angles = torch.linspace(0, 1, num_angles + 1)[:-1]
+        distances = torch.linspace(0, 1, self.num_clusters + 2, dtype=torch.float)[1:-1]
+        angles = angles.view(num_angles, 1).expand(num_angles, self.num_clusters)
+        distances = distances.view(1, self.num_clusters).expand(num_angles, self.num_clusters)
+        return torch.cat([angles[..., None], distances[..., None]], dim=-1).flatten(0, 1)
+
+    def forward(self, mlvl_feats, lss_bev_feats, radar_bev_feats, img_metas):
+        """racformer_head.py:82-134, eval branch of prepare_for_dn_input (:142-145, :241-245)."""
+        if self.training:
+            raise NotImplementedError("racformer_amd: training (query denoising, losses) is out of scope")
+        B = lss_bev_feats.shape[0]
+        Q = self.num_query
+        query_bbox = self.init_query_bbox.weight.view(1, Q, 10).repeat(B, 1, 1)
+        feat = self.label_enc.weight[self.num_classes].repeat(Q, 1)
+        query_feat = torch.cat([feat, feat.new_zeros(Q, 1)], dim=1).repeat(B, 1, 1)
+        cls_scores, bbox_preds = self.transformer(query_bbox, query_feat, mlvl_feats, lss_bev_feats,
+                                                  radar_bev_feats, attn_mask=None, img_metas=img_metas)
+        pc = self.pc_range
+        lo = bbox_preds.new_tensor(pc[0:3])
+        span = bbox_preds.new_tensor([pc[3] - pc[0], pc[4] - pc[1], pc[5] - pc[2]])
+        xyz = bbox_preds[..., 0:3] * span + lo
+        bbox_preds = torch.cat([xyz[..., 0:2], bbox_preds[..., 3:5], xyz[..., 2:3], bbox_preds[..., 5:10]], dim=-1)
+        return {"all_cls_scores": cls_scores, "all_bbox_preds": bbox_preds, "enc_cls_scores": None,
+                "enc_bbox_preds": None}
+
+    def get_bboxes(self, preds_dicts, img_metas, rescale=False):
+        """racformer_head.py:488-507 (VERSION 'v1.0.0').  Boxes are returned as a plain [n,9] tensor
+        (x, y, z_bottom, w, l, h, yaw, vx, vy) -- mmdet3d's LiDARInstance3DBoxes wrapper is not a
+        dependency here."""
+        ret_list = []
+        for preds in self.bbox_coder.decode(preds_dicts):
+            bboxes = preds["bboxes"]
+            bboxes = torch.cat([bboxes[:, :2], bboxes[:, 2:3] - bboxes[:, 5:6] * 0.5, bboxes[:, 3:]], dim=1)
+            ret_list.append([bboxes, preds["scores"], preds["labels"]])
+        return ret_list
+
+    def get_detections_fixed(self, preds_dicts):
+        """Shape-static detections for the data-parallel all-gather: [B, max_num, 11] =
+        (9 box dims with z at the box bottom, score, label); rows that fail the centre-range /
+        score masks carry score = -1.  Same numbers as get_bboxes, no host synchronisation."""
+        cls, box = preds_dicts["all_cls_scores"][-1], preds_dicts["all_bbox_preds"][-1]
+        out = []
+        for i in range(cls.size(0)):
+            b, s, l, keep = self.bbox_coder.topk_fixed(cls[i], box[i])
+            b = torch.cat([b[:, :2], b[:, 2:3] - b[:, 5:6] * 0.5, b[:, 3:]], dim=1)
+            s = torch.where(keep, s, torch.full_like(s, -1.0))
+            out.append(torch.cat([b, s[:, None], l[:, None].to(b.dtype)], dim=1))
+        return torch.stack(out)

@@ -1,0 +1,71 @@
+"""Drop-in for ``models/multi_scale_deformable_attn_function.py`` of the reference:
+``MultiScaleDeformableAttnFunction_fp32`` / ``_fp16`` with the same ``apply`` signature
+(:93-128), on top of ``rac_msda_fwd`` (hand-written HIP, racformer_amd/csrc/msda_fwd.hip).
+Forward only this round."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _host_i64(x):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().reshape(-1).tolist()  # tiny D2H; callers on the hot path pass lists
+    else:
+        x = [int(v) for row in x for v in (row if isinstance(row, (list, tuple)) else [row])]
+    return (ctypes.c_int64 * len(x))(*[int(v) for v in x]), len(x)
+
+
+def msda_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+                 out=None):
+    """value [bs,keys,heads,dim] (f32/bf16), sampling_locations [bs,Q,heads,L,P,2],
+    attention_weights [bs,Q,heads,L,P] -> [bs,Q,heads*dim] f32."""
+    _lib.require_gpu(value, sampling_locations, attention_weights, what="ms_deform_attn_forward")
+    bs, keys, heads, dim = value.shape
+    _, Q, h2, L, P, two = sampling_locations.shape
+    if h2 != heads or two != 2 or tuple(attention_weights.shape) != (bs, Q, heads, L, P):
+        raise RuntimeError("ms_deform_attn_forward: inconsistent shapes")
+    shapes, n = _host_i64(spatial_shapes)
+    starts, m = _host_i64(level_start_index)
+    if n != 2 * L or m != L:
+        raise RuntimeError("ms_deform_attn_forward: spatial_shapes must be [L,2], level_start_index [L]")
+    if sampling_locations.dtype != torch.float32 or attention_weights.dtype != torch.float32:
+        raise RuntimeError("ms_deform_attn_forward: locations / weights must be float32")
+    if out is None:
+        out = torch.empty(bs, Q, heads * dim, device=value.device, dtype=torch.float32)
+    ev = _lib.timer.record("msda_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_msda_fwd(_lib.ptr(value), shapes, starts, _lib.ptr(sampling_locations),
+                                 _lib.ptr(attention_weights), _lib.ptr(out), bs, keys, heads, dim, Q, L, P,
+                                 _lib.dtype_code(value), _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_msda_fwd")
+    return out
+
+
+class MultiScaleDeformableAttnFunction_fp32(torch.autograd.Function):
+    """apply(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+    attention_weights, im2col_step) -> [bs, num_queries, embed_dims]; inputs are cast to float32
+    as the reference's ``custom_fwd(cast_inputs=torch.float32)`` does (:93)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        bs = value.shape[0]
+        step = min(bs, int(im2col_step))
+        if step > 0 and bs % step != 0:
+            raise RuntimeError(f"batch({bs}) must divide im2col_step({step})")  # mmcv's check
+        return msda_forward(value.float().contiguous(), value_spatial_shapes, value_level_start_index,
+                            sampling_locations.float().contiguous(), attention_weights.float().contiguous())
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise NotImplementedError("racformer_amd: MSDA backward is not built yet (inference path only)")
+
+
+class MultiScaleDeformableAttnFunction_fp16(MultiScaleDeformableAttnFunction_fp32):
+    """The reference routes fp16 values to the fp32 function as well
+    (models/bev_self_attention.py:195-198); kept for name compatibility."""

@@ -1,0 +1,638 @@
+"""MI355X-native counterparts of the reference's decoder modules
+(``models/racformer_transformer.py``, ``models/bev_self_attention.py``,
+``models/sparsebev_sampling.py``): same class names, constructor signatures, forward signatures
+and ``state_dict`` keys, so a reference checkpoint's
+``pts_bbox_head.transformer.*`` tensors load unchanged and configs can name the classes as before.
+
+What is different is the execution plan, designed for one MI355X per sample:
+  * the two gather operators run as hand-written HIP kernels through the C-ABI
+    (``rac_msmv_fwd`` writing the mixing-ready ``[B,Q,G,T*P,C]`` layout, ``rac_msda_fwd``);
+  * everything that does not depend on the queries is computed ONCE per forward instead of once
+    per decoder layer -- the six layers share one set of weights
+    (racformer_transformer.py:84-89), so ``temporal_encoder(radar_bev)``, ``bev + pos`` and
+    ``value_proj`` are identical in all six iterations (254 GFLOP/layer in the reference);
+  * the pyramid regroup is one HIP transpose kernel (``rac_regroup_fwd``);
+  * no host<->device traffic inside the layer loop (the reference uploads ``linspace`` and shape
+    tensors every layer, racformer_transformer.py:395,515, bev_self_attention.py:189-190).
+There is no CPU fallback: inputs must live on the GPU and the HIP library must be built.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
+from .msda import msda_forward
+from .msmv import msmv_forward
+
+try:  # registry decorators are applied only if mmdet happens to be importable
+    from mmdet.models.utils.builder import TRANSFORMER as _TRANSFORMER
+    _register = _TRANSFORMER.register_module()
+except Exception:  # noqa: BLE001
+    def _register(cls):
+        return cls
+
+_TWO_PI = 2 * math.pi
+
+
+# ------------------------------------------------------------------------------- small blocks
+class _AttnParams(nn.Module):
+    """Parameter container with nn.MultiheadAttention's key names (in_proj_*, out_proj.*)."""
+
+    def __init__(self, embed_dims):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dims, embed_dims))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dims))
+        self.out_proj = nn.Linear(embed_dims, embed_dims)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class _MHAHolder(nn.Module):
+    """Stands where mmcv's MultiheadAttention wrapper stands (key prefix ``attention.attn``)."""
+
+    def __init__(self, embed_dims):
+        super().__init__()
+        self.attn = _AttnParams(embed_dims)
+
+
+class _FFN(nn.Module):
+    """mmcv FFN(embed, feedforward_channels) key layout: layers.0.0 / layers.1, + identity."""
+
+    def __init__(self, embed_dims, feedforward_channels):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(0.0)),
+            nn.Linear(feedforward_channels, embed_dims), nn.Dropout(0.0))
+
+    def forward(self, x):
+        return x + self.layers(x)
+
+
+class _LearnedPositionalEncoding(nn.Module):
+    """mmdet LearnedPositionalEncoding key layout (row_embed / col_embed)."""
+
+    def __init__(self, num_feats, row_num_embed, col_num_embed):
+        super().__init__()
+        self.row_embed = nn.Embedding(row_num_embed, num_feats)
+        self.col_embed = nn.Embedding(col_num_embed, num_feats)
+
+    def grid(self, h, w):
+        col = self.col_embed.weight[:w]
+        row = self.row_embed.weight[:h]
+        pos = torch.cat([col[None].expand(h, w, -1), row[:, None].expand(h, w, -1)], dim=-1)
+        return pos.permute(2, 0, 1)  # [2*num_feats, h, w]
+
+
+# ------------------------------------------------------------------------------- self attention
+class ScaleAdaptiveSelfAttention(nn.Module):
+    """racformer_transformer.py:282-335.  mask[b,h,i,j] = -||c_i-c_j|| * tau[b,h,i]."""
+
+    def __init__(self, embed_dims=256, num_heads=8, dropout=0.1, pc_range=[], init_cfg=None):
+        super().__init__()
+        self.pc_range = pc_range
+        self.embed_dims = embed_dims
+        self.num_heads = num_heads
+        self.attention = _MHAHolder(embed_dims)
+        self.gen_tau = nn.Linear(embed_dims, num_heads)
+
+    @torch.no_grad()
+    def init_weights(self):
+        nn.init.zeros_(self.gen_tau.weight)
+        nn.init.uniform_(self.gen_tau.bias, 0.0, 2.0)
+
+    def forward(self, query_bbox, query_feat, pre_attn_mask=None):
+        B, Q, E = query_feat.shape
+        Hn, d = self.num_heads, E // self.num_heads
+        centers = decode_bbox(theta_d2xy_coods(query_bbox), self.pc_range)[..., :2]
+        dist = -torch.cdist(centers, centers, compute_mode="donot_use_mm_for_euclid_dist")  # [B,Q,Q]
+        tau = self.gen_tau(query_feat).permute(0, 2, 1)                                     # [B,H,Q]
+        mask = dist[:, None] * tau[..., None]
+        if pre_attn_mask is not None:
+            mask[:, :, pre_attn_mask] = float("-inf")
+        p = self.attention.attn
+        qkv = F.linear(query_feat, p.in_proj_weight, p.in_proj_bias).view(B, Q, 3, Hn, d)
+        q = qkv[:, :, 0].permute(0, 2, 1, 3) * math.sqrt(1.0 / d)
+        k = qkv[:, :, 1].permute(0, 2, 1, 3)
+        v = qkv[:, :, 2].permute(0, 2, 1, 3)
+        attn = torch.softmax(mask + q @ k.transpose(-1, -2), dim=-1)
+        o = (attn @ v).permute(0, 2, 1, 3).reshape(B, Q, E)
+        return query_feat + p.out_proj(o)
+
+
+# ------------------------------------------------------------------------------- keypoints
+def make_sample_points(query_bbox, offset, pc_range):
+    """sparsebev_sampling.py:8-25: p = xyz + R_z(yaw) (wlh * offset)."""
+    d = decode_bbox(query_bbox, pc_range)
+    xyz, wlh, ang = d[..., 0:3], d[..., 3:6], d[..., 6:7]
+    delta = wlh[:, :, None, :] * offset[..., 0:3]
+    c, s = torch.cos(ang)[..., None, :], torch.sin(ang)[..., None, :]
+    rot = torch.cat([delta[..., 0:1] * c - delta[..., 1:2] * s,
+                     delta[..., 0:1] * s + delta[..., 1:2] * c, delta[..., 2:3]], dim=-1)
+    return xyz[:, :, None, :] + rot
+
+
+def _warp_to_polar(points_xy, vel, time_diff, pc_range):
+    """velocity warp + normalise + polar (racformer_transformer.py:379-393 / :501-512).
+    points_xy [B,Q,1,G,P,2] -> theta, d each [B,Q,T,G,P,1]."""
+    shift = (vel[:, :, None, :] * time_diff[:, None, :, None])[:, :, :, None, None, :]   # [B,Q,T,1,1,2]
+    xy = points_xy - shift
+    x = (xy[..., 0:1] - pc_range[0]) / (pc_range[3] - pc_range[0])
+    y = (xy[..., 1:2] - pc_range[1]) / (pc_range[4] - pc_range[1])
+    pol = xy2theta_d_coods(torch.cat([x, y], dim=-1))
+    return pol[..., 0:1], pol[..., 1:2]
+
+
+class RaCFormerSampling(nn.Module):
+    """Adaptive spatio-temporal sampling (racformer_transformer.py:338-427)."""
+
+    def __init__(self, embed_dims=256, num_frames=4, num_groups=4, num_points=8, num_levels=4,
+                 depth_num=15, pc_range=[], init_cfg=None):
+        super().__init__()
+        self.num_frames, self.num_points, self.num_groups = num_frames, num_points, num_groups
+        self.num_levels, self.pc_range, self.depth_num = num_levels, pc_range, depth_num
+        self.ray_points_offset = nn.Linear(embed_dims, depth_num)
+        self.sampling_offset = nn.Linear(embed_dims, depth_num * num_groups * num_points * 3)
+        self.scale_weights = nn.Linear(embed_dims, num_groups * num_frames * depth_num * num_points * num_levels)
+
+    def init_weights(self):
+        bias = self.sampling_offset.bias.data.view(self.depth_num * self.num_groups * self.num_points, 3)
+        nn.init.zeros_(self.sampling_offset.weight)
+        nn.init.uniform_(bias[:, 0:3], -0.5, 0.5)
+
+    def keypoints(self, query_ray, query_feat, time_diff, d_region):
+        """-> metric points [B,Q,T,G,P,3], scale weights [B,Q,G,T,P,L] (softmax over L)."""
+        B, Q, _ = query_ray.shape
+        T, G, NP, D, L = self.num_frames, self.num_groups, self.num_points, self.depth_num, self.num_levels
+        pc = self.pc_range
+        qb = theta_d2xy_coods(query_ray)
+        off = self.sampling_offset(query_feat).view(B, Q, G * NP * D, 3)
+        pts = make_sample_points(qb, off, pc).view(B, Q, 1, G, NP * D, 3)
+        theta, dist = _warp_to_polar(pts[..., 0:2], query_ray[..., 8:], time_diff, pc)
+        base = torch.linspace(-d_region, d_region, D, device=query_feat.device, dtype=query_feat.dtype)
+        d_off = base + (torch.sigmoid(self.ray_points_offset(query_feat)) * 2 - 1) * d_region / D / 2  # [B,Q,D]
+        dist = (dist.view(B, Q, T, G, NP, D) + d_off[:, :, None, None, None, :]).reshape(B, Q, T, G, NP * D, 1)
+        xy = theta_d2xy_coods(torch.cat([theta, dist], dim=-1))
+        px = xy[..., 0:1] * (pc[3] - pc[0]) + pc[0]
+        py = xy[..., 1:2] * (pc[4] - pc[1]) + pc[1]
+        pz = pts[..., 2:3].expand(B, Q, T, G, NP * D, 1)
+        points = torch.cat([px, py, pz], dim=-1)
+        sw = self.scale_weights(query_feat).view(B, Q, G, T, D * NP, L)
+        return points, torch.softmax(sw, dim=-1)
+
+    def forward(self, query_ray, query_feat, mlvl_feats, img_metas, d_region=0.1):
+        image_h, image_w, _ = img_metas[0]["img_shape"][0]
+        points, sw = self.keypoints(query_ray, query_feat, img_metas[0]["time_diff"], d_region)
+        return sampling_4d(points, mlvl_feats, sw, img_metas[0]["lidar2img"], image_h, image_w)
+
+
+def sampling_4d(sample_points, mlvl_feats, scale_weights, lidar2img, image_h, image_w, aggregate=True,
+                eps=1e-5):
+    """sparsebev_sampling.py:28-134 on the HIP msmv operator.
+    sample_points [B,Q,T,G,P,3]; mlvl_feats[l] [B*T*G,N,H,W,C] channel-last; scale_weights
+    [B,Q,G,T,P,L]; lidar2img [B,T*N,4,4] -> [B,Q,G,T*P,C].  Projection, validity, first-valid-view
+    selection and the (b,g,t)-vs-(b,t,g) weight slot order (:113-120) are as in the reference."""
+    if not aggregate:
+        raise NotImplementedError("sampling_4d(aggregate=False) is not on the inference path")
+    B, Q, T, G, P, _ = sample_points.shape
+    N = lidar2img.shape[1] // T
+    m = lidar2img.view(B, T, N, 1, 1, 4, 4)
+    p = sample_points.permute(0, 2, 1, 3, 4, 5).reshape(B, T, 1, Q, G * P, 3)
+    x, y, z = p[..., 0], p[..., 1], p[..., 2]
+    cx = m[..., 0, 0] * x + m[..., 0, 1] * y + m[..., 0, 2] * z + m[..., 0, 3]
+    cy = m[..., 1, 0] * x + m[..., 1, 1] * y + m[..., 1, 2] * z + m[..., 1, 3]
+    homo = m[..., 2, 0] * x + m[..., 2, 1] * y + m[..., 2, 2] * z + m[..., 2, 3]     # [B,T,N,Q,GP]
+    hz = torch.clamp(homo, min=eps)
+    u = cx / hz / image_w
+    v = cy / hz / image_h
+    valid = (homo > eps) & (v > 0.0) & (v < 1.0) & (u > 0.0) & (u < 1.0)
+    i_view = torch.argmax(valid.to(torch.uint8), dim=2, keepdim=True)                 # first valid / 0
+    u_sel = torch.gather(u, 2, i_view)[:, :, 0]
+    v_sel = torch.gather(v, 2, i_view)[:, :, 0]                                      # [B,T,Q,GP]
+    loc = torch.stack([u_sel, v_sel, i_view[:, :, 0].to(u.dtype) / (N - 1)], dim=-1)
+    loc = loc.view(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * T * G, Q, P, 3).contiguous()
+    L = scale_weights.shape[-1]
+    w = scale_weights.reshape(B, Q, G, T, P, L).permute(0, 2, 3, 1, 4, 5).reshape(B * G * T, Q, P, L).contiguous()
+    return msmv_forward(mlvl_feats, loc, w, out_layout=_lib.OUT_BQGTPC, num_frames=T, num_groups=G)
+
+
+# ------------------------------------------------------------------------------- BEV branch
+class ConvGRUCell(nn.Module):
+    def __init__(self, input_channels, hidden_channels, kernel_size):
+        super().__init__()
+        self.hidden_channels = hidden_channels
+        self.gates_conv = nn.Conv2d(input_channels + hidden_channels, 3 * hidden_channels,
+                                    kernel_size=kernel_size, padding=kernel_size // 2)
+        self.matching_layer = nn.Conv2d(hidden_channels, input_channels, 1)
+
+    def forward(self, x, h_prev):
+        gates = self.gates_conv(torch.cat([x, self.matching_layer(h_prev)], dim=1))
+        z_gate, r_gate, cand = torch.split(gates, self.hidden_channels, dim=1)
+        z, r = torch.sigmoid(z_gate), torch.sigmoid(r_gate)
+        cand = torch.tanh(cand + r * h_prev)
+        return (1 - z) * h_prev + z * cand
+
+
+class ConvGRU(nn.Module):
+    """racformer_transformer.py:665-693: only frames t < min(4,T) are updated."""
+
+    def __init__(self, input_channels, hidden_channels, kernel_size):
+        super().__init__()
+        self.convGRUCell = ConvGRUCell(input_channels, hidden_channels, kernel_size)
+        self.hidden_channels = hidden_channels
+
+    def forward(self, x):
+        B, T, C, H, W = x.shape
+        h = torch.zeros(B, self.hidden_channels, H, W, device=x.device, dtype=x.dtype)
+        out = torch.zeros(B, T, self.hidden_channels, H, W, device=x.device, dtype=x.dtype)
+        for t in range(min(4, T)):
+            h = self.convGRUCell(x[:, t], h)
+            out[:, t] = h
+        return out
+
+
+class RadarBEVTemporalEncoder(nn.Module):
+    """racformer_transformer.py:618-663"""
+
+    def __init__(self, embed_dims=256, hidden_dims=64, num_frames=8, kernel_size=3, downsample_ratio=2,
+                 init_cfg=None):
+        super().__init__()
+        self.num_frames, self.embed_dims, self.hidden_dims = num_frames, embed_dims, hidden_dims
+        self.convGRU = ConvGRU(hidden_dims, hidden_dims, kernel_size)
+        self.temporal_fusion = nn.Conv2d(embed_dims + hidden_dims, embed_dims, kernel_size, padding=kernel_size // 2)
+        self.downsample_ratio = downsample_ratio
+        self.downsample = nn.Conv2d(embed_dims, hidden_dims, kernel_size=3, stride=downsample_ratio, padding=1)
+        self.upsample = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
+                                      nn.Conv2d(hidden_dims, hidden_dims, kernel_size=3, padding=1))
+
+    def init_weights(self):
+        pass
+
+    def forward(self, bev_feats):
+        B, T, C, H, W = bev_feats.shape
+        r = self.downsample_ratio
+        down = self.downsample(bev_feats.flatten(0, 1)).reshape(B, T, self.hidden_dims, H // r, W // r)
+        hid = self.upsample(self.convGRU(down).flatten(0, 1))
+        cat = torch.cat([bev_feats.flatten(0, 1), hid], dim=1)
+        return self.temporal_fusion(cat).reshape(B, T, C, H, W)
+
+
+class BEVSelfAttention(nn.Module):
+    """bev_self_attention.py:22-225 (deformable attention over T BEV maps + learned frame fusion)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, num_bev_queue=2,
+                 im2col_step=64, dropout=0.1, queue_weight=False, batch_first=True, norm_cfg=None,
+                 init_cfg=None):
+        super().__init__()
+        if embed_dims % num_heads != 0:
+            raise ValueError(f"embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}")
+        self.im2col_step, self.embed_dims, self.num_levels = im2col_step, embed_dims, num_levels
+        self.num_heads, self.num_points, self.num_bev_queue = num_heads, num_points, num_bev_queue
+        self.queue_weight = queue_weight
+        if queue_weight:
+            self.bev_queue_weight = nn.Linear(embed_dims, num_bev_queue)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in (self.value_proj, self.output_proj) + ((self.bev_queue_weight,) if self.queue_weight else ()):
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.constant_(m.bias, 0.0)
+
+    def project_value(self, value_maps):
+        """value_maps [B,T,C,H,W] -> [B*T, H*W, heads, C/heads] (bev_self_attention.py:162-174).
+        Query-independent: the decoder calls this once per forward, not once per layer."""
+        B, T, C, H, W = value_maps.shape
+        v = value_maps.reshape(B * T, C, H * W).permute(0, 2, 1)
+        return self.value_proj(v).reshape(B * T, H * W, self.num_heads, C // self.num_heads).contiguous()
+
+    def attend(self, query, value, sampling_locations, attention_weights, spatial_shapes, identity=None):
+        """value: projected [B*T, HW, heads, D]; sampling_locations [B,Q,heads,T,P,2];
+        attention_weights [B,Q,heads,T,L=1,P]."""
+        B, Q, C = query.shape
+        T, Hn, P = self.num_bev_queue, self.num_heads, self.num_points
+        if identity is None:
+            identity = query
+        loc = sampling_locations.view(B, Q, Hn, T, self.num_levels, P, 2).permute(3, 0, 1, 2, 4, 5, 6) \
+            .reshape(B * T, Q, Hn, self.num_levels, P, 2).contiguous()
+        aw = attention_weights.view(B, Q, Hn, T, self.num_levels, P).permute(3, 0, 1, 2, 4, 5) \
+            .reshape(B * T, Q, Hn, self.num_levels, P).contiguous()
+        out = msda_forward(value, [list(spatial_shapes)], [0], loc, aw)                   # [B*T,Q,C]
+        out = out.permute(1, 2, 0).reshape(Q, C, B, T)
+        if self.queue_weight:
+            qw = self.bev_queue_weight(query).permute(1, 0, 2).reshape(Q, 1, B, T)
+            out = torch.sum(out * torch.softmax(qw, dim=-1), dim=-1)
+        else:
+            out = out.sum(-1) / T
+        return self.output_proj(out.permute(2, 0, 1)) + identity
+
+    def forward(self, query, value, sampling_locations, attention_weights, key_padding_mask=None,
+                identity=None, spatial_shapes=None, **kwargs):
+        """Reference signature: ``value`` is the raw [B,T,C,H,W] map stack (already bev+pos)."""
+        if key_padding_mask is not None:
+            raise NotImplementedError("key_padding_mask is unused on the RaCFormer path")
+        return self.attend(query, self.project_value(value), sampling_locations, attention_weights,
+                           spatial_shapes, identity)
+
+
+class BEVSampling(nn.Module):
+    """racformer_transformer.py:429-546"""
+
+    def __init__(self, embed_dims=256, num_frames=4, num_points=8, num_heads=4, num_levels=4, pc_range=[],
+                 spatial_shapes=(128, 128), depth_num=30, temp_radar=False, init_cfg=None):
+        super().__init__()
+        self.num_frames, self.num_points, self.num_heads = num_frames, num_points, num_heads
+        self.num_levels, self.embed_dims, self.pc_range, self.depth_num = num_levels, embed_dims, pc_range, depth_num
+        self.ray_points_offset = nn.Linear(embed_dims, depth_num)
+        self.sampling_offset = nn.Linear(embed_dims, depth_num * num_heads * num_points * 2)
+        self.scale_weights = nn.Linear(embed_dims, num_heads * num_levels * depth_num * num_points)
+        self.positional_encoding = _LearnedPositionalEncoding(128, row_num_embed=spatial_shapes[1],
+                                                              col_num_embed=spatial_shapes[0])
+        self.attention = BEVSelfAttention(embed_dims=embed_dims, num_heads=4, num_levels=1,
+                                          num_points=num_points * depth_num, num_bev_queue=num_frames,
+                                          queue_weight=True)
+        self.temp_radar = temp_radar
+        if temp_radar:
+            self.temporal_encoder = RadarBEVTemporalEncoder(embed_dims, 64, num_frames)
+
+    def init_weights(self):
+        bias = self.sampling_offset.bias.data.view(self.depth_num * self.num_heads * self.num_points, 2)
+        nn.init.zeros_(self.sampling_offset.weight)
+        nn.init.uniform_(bias[:, 0:2], -0.5, 0.5)
+        self.attention.init_weights()
+
+    def prepare_value(self, bev_feats):
+        """Query-independent half of inner_forward (:484-485, :532-537 + value_proj): temporal
+        encoder (radar only), + learned positional encoding, value projection."""
+        if self.temp_radar:
+            bev_feats = self.temporal_encoder(bev_feats)
+        H, W = bev_feats.shape[-2:]
+        pos = self.positional_encoding.grid(H, W).to(bev_feats.dtype)
+        return self.attention.project_value(bev_feats + pos[None, None]), (H, W)
+
+    def keypoints(self, query_ray, query_feat, time_diff, d_region):
+        """-> loc [B,Q,heads,T,P,2] in [0,1], weights [B,Q,heads,T,1,P] (:490-529)."""
+        B, Q, _ = query_ray.shape
+        T, Hn, NP, D = self.num_frames, self.num_heads, self.num_points, self.depth_num
+        pc = self.pc_range
+        qb = theta_d2xy_coods(query_ray)
+        off = self.sampling_offset(query_feat).view(B, Q, Hn * NP * D, 2)
+        off = torch.cat([off, torch.zeros_like(off[..., 0:1])], dim=-1)
+        pts = make_sample_points(qb, off, pc).view(B, Q, 1, Hn, NP * D, 3)
+        theta, dist = _warp_to_polar(pts[..., 0:2], query_ray[..., 8:], time_diff, pc)
+        base = torch.linspace(-d_region, d_region, D, device=query_feat.device, dtype=query_feat.dtype)
+        d_off = base + (torch.sigmoid(self.ray_points_offset(query_feat)) * 2 - 1) * d_region / D / 2
+        dist = (dist.view(B, Q, T, Hn, NP, D) + d_off[:, :, None, None, None, :]).reshape(B, Q, T, Hn, NP * D, 1)
+        loc = theta_d2xy_coods(torch.cat([theta, dist], dim=-1)).permute(0, 1, 3, 2, 4, 5).contiguous()
+        sw = self.scale_weights(query_feat).view(B, Q, Hn, 1, self.num_levels, D * NP)
+        sw = torch.softmax(sw, dim=-1).expand(B, Q, Hn, T, self.num_levels, D * NP).contiguous()
+        return loc, sw
+
+    def attend_prepared(self, query_ray, query_feat, value, hw, time_diff, d_region):
+        loc, sw = self.keypoints(query_ray, query_feat, time_diff, d_region)
+        return self.attention.attend(query_feat, value, loc, sw, hw)
+
+    def forward(self, query_ray, query_feat, bev_feats, img_metas, d_region=0.1):
+        value, hw = self.prepare_value(bev_feats)
+        return self.attend_prepared(query_ray, query_feat, value, hw, img_metas[0]["time_diff"], d_region)
+
+
+# ------------------------------------------------------------------------------- mixing
+class AdaptiveMixing(nn.Module):
+    """racformer_transformer.py:549-616"""
+
+    def __init__(self, in_dim, in_points, n_groups=1, query_dim=None, out_dim=None, out_points=None):
+        super().__init__()
+        out_dim = out_dim if out_dim is not None else in_dim
+        out_points = out_points if out_points is not None else in_points
+        query_dim = query_dim if query_dim is not None else in_dim
+        self.query_dim, self.in_dim, self.in_points, self.n_groups = query_dim, in_dim, in_points, n_groups
+        self.out_dim, self.out_points = out_dim, out_points
+        self.eff_in_dim, self.eff_out_dim = in_dim // n_groups, out_dim // n_groups
+        self.m_parameters = self.eff_in_dim * self.eff_out_dim
+        self.s_parameters = self.in_points * self.out_points
+        self.total_parameters = self.m_parameters + self.s_parameters
+        self.parameter_generator = nn.Linear(self.query_dim, self.n_groups * self.total_parameters)
+        self.out_proj = nn.Linear(self.eff_out_dim * self.out_points * self.n_groups, self.query_dim)
+
+    @torch.no_grad()
+    def init_weights(self):
+        nn.init.zeros_(self.parameter_generator.weight)
+
+    def forward(self, x, query):
+        B, Q, G, P, C = x.shape
+        assert G == self.n_groups and P == self.in_points and C == self.eff_in_dim
+        params = self.parameter_generator(query).reshape(B * Q, G, -1)
+        M, S = params.split([self.m_parameters, self.s_parameters], 2)
+        M = M.reshape(B * Q, G, self.eff_in_dim, self.eff_out_dim)
+        S = S.reshape(B * Q, G, self.out_points, self.in_points)
+        out = torch.matmul(x.reshape(B * Q, G, P, C), M)
+        out = F.relu(F.layer_norm(out, [out.size(-2), out.size(-1)]))
+        out = torch.matmul(S, out)
+        out = F.relu(F.layer_norm(out, [out.size(-2), out.size(-1)]))
+        return query + self.out_proj(out.reshape(B, Q, -1))
+
+
+# ------------------------------------------------------------------------------- decoder
+class RaCFormerTransformerDecoderLayer(nn.Module):
+    """racformer_transformer.py:145-279"""
+
+    def __init__(self, embed_dims, num_frames=8, num_points=4, num_points_bev=4, num_levels=4, num_classes=10,
+                 code_size=10, num_cls_fcs=2, num_reg_fcs=2, img_depth_num=3, bev_depth_num=5, num_ray=150,
+                 pc_range=[], d_region_list=[0.15, 0.1, 0.1, 0.08, 0.08, 0.05], spatial_shapes=(128, 128),
+                 init_cfg=None):
+        super().__init__()
+        self.embed_dims, self.num_classes, self.code_size, self.pc_range = embed_dims, num_classes, code_size, pc_range
+        self.position_encoder = nn.Sequential(
+            nn.Linear(3, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True),
+            nn.Linear(embed_dims, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True))
+        self.self_attn = ScaleAdaptiveSelfAttention(embed_dims, num_heads=8, dropout=0.1, pc_range=pc_range)
+        self.sampling = RaCFormerSampling(embed_dims, num_frames=num_frames, num_groups=4, num_points=num_points,
+                                          num_levels=num_levels, depth_num=img_depth_num, pc_range=pc_range)
+        self.sampling_radar_bev = BEVSampling(embed_dims, num_frames=num_frames, num_heads=4,
+                                              num_points=num_points_bev, num_levels=1, pc_range=pc_range,
+                                              depth_num=bev_depth_num, spatial_shapes=spatial_shapes,
+                                              temp_radar=True)
+        self.sampling_lss_bev = BEVSampling(embed_dims, num_frames=num_frames, num_heads=4,
+                                            num_points=num_points_bev, num_levels=1, pc_range=pc_range,
+                                            depth_num=bev_depth_num, spatial_shapes=spatial_shapes)
+        self.mixing = AdaptiveMixing(in_dim=embed_dims, in_points=num_points * num_frames * img_depth_num,
+                                     n_groups=4, out_points=128)
+        self.ffn = _FFN(embed_dims, 512)
+        self.norm1 = nn.LayerNorm(embed_dims)
+        self.norm2 = nn.LayerNorm(embed_dims)
+        self.norm3 = nn.LayerNorm(embed_dims)
+        self.fusion = nn.Linear(embed_dims * 3, embed_dims)
+        self.norm_radar_bev = nn.LayerNorm(embed_dims)
+        self.norm_lss_bev = nn.LayerNorm(embed_dims)
+        self.norm_fusion = nn.LayerNorm(embed_dims)
+        cls_branch = []
+        for _ in range(num_cls_fcs):
+            cls_branch += [nn.Linear(embed_dims, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True)]
+        cls_branch.append(nn.Linear(embed_dims, num_classes))
+        self.cls_branch = nn.Sequential(*cls_branch)
+        reg_branch = []
+        for _ in range(num_reg_fcs):
+            reg_branch += [nn.Linear(embed_dims, embed_dims), nn.ReLU(inplace=True)]
+        reg_branch.append(nn.Linear(embed_dims, code_size))
+        self.reg_branch = nn.Sequential(*reg_branch)
+        self.d_region_list = d_region_list
+        self.num_ray = num_ray
+
+    @torch.no_grad()
+    def init_weights(self):
+        self.self_attn.init_weights()
+        self.sampling.init_weights()
+        self.mixing.init_weights()
+        self.sampling_radar_bev.init_weights()
+        self.sampling_lss_bev.init_weights()
+        nn.init.constant_(self.cls_branch[-1].bias, float(-math.log((1 - 0.01) / 0.01)))
+        nn.init.xavier_uniform_(self.fusion.weight)
+        nn.init.constant_(self.fusion.bias, 0.0)
+
+    def refine_bbox(self, bbox_proposal, bbox_delta):
+        dz_new = torch.sigmoid(bbox_delta[..., 1:3] + inverse_sigmoid(bbox_proposal[..., 1:3]))
+        theta = bbox_proposal[..., 0:1] + (torch.sigmoid(bbox_delta[..., 0:1]) * 2 - 1) / self.num_ray
+        return torch.cat([theta, dz_new, bbox_delta[..., 3:]], dim=-1)
+
+    def prepare(self, lss_bev_feats, radar_bev_feats):
+        """Layer-invariant tensors (computed once per forward)."""
+        radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats)
+        lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
+        return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw)
+
+    def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
+                layer=0, prepared=None, stages=None):
+        if prepared is None:
+            prepared = self.prepare(lss_bev_feats, radar_bev_feats)
+        meta = img_metas[0]
+        time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
+        query_pos = self.position_encoder(query_bbox[..., :3])
+        query_feat = query_feat + query_pos
+        sa = self.self_attn(query_bbox, query_feat, attn_mask)
+        query_feat = self.norm1(sa)
+        radar_raw = self.sampling_radar_bev.attend_prepared(query_bbox, query_feat, prepared["radar_value"],
+                                                            prepared["radar_hw"], time_diff, d_region)
+        lss_raw = self.sampling_lss_bev.attend_prepared(query_bbox, query_feat, prepared["lss_value"],
+                                                        prepared["lss_hw"], time_diff, d_region)
+        query_radar_feat = self.norm_radar_bev(radar_raw)
+        query_lss_feat = self.norm_lss_bev(lss_raw)
+        sampled_feat = self.sampling(query_bbox, query_feat, mlvl_feats, img_metas, d_region=d_region)
+        mixed = self.mixing(sampled_feat, query_feat)
+        query_feat = self.norm2(mixed)
+        query_feat = self.norm_fusion(self.fusion(torch.cat((query_feat, query_radar_feat, query_lss_feat), dim=-1)))
+        ffn_out = self.ffn(query_feat)
+        query_feat = self.norm3(ffn_out)
+        cls_score = self.cls_branch(query_feat)
+        bbox_pred = self.refine_bbox(query_bbox, self.reg_branch(query_feat))
+        if time_diff.shape[1] > 1:
+            td = meta["time_diff_safe"][:, 1:2, None]
+            bbox_pred = torch.cat([bbox_pred[..., :8], bbox_pred[..., 8:] / td], dim=-1)
+        if stages is not None:
+            stages.update(position_encoder=query_pos, self_attn=sa, sampling_radar_bev=radar_raw,
+                          sampling_lss_bev=lss_raw, sampling=sampled_feat, mixing=mixed, ffn=ffn_out)
+        return query_feat, cls_score, bbox_pred
+
+
+def regroup_pyramid(mlvl_feats, num_cams, groups=4, out_dtype=torch.float32):
+    """racformer_transformer.py:112-124 as one HIP transpose per level:
+    [B,T*N,G*C,H,W] -> [B*T*G, N, H, W, C]."""
+    out = []
+    for feat in mlvl_feats:
+        B, TN, GC, H, W = feat.shape
+        if TN % num_cams != 0 or GC % groups != 0:
+            raise RuntimeError("regroup_pyramid: expected [B, T*N, G*C, H, W]")
+        N, T, C = num_cams, TN // num_cams, GC // groups
+        feat = feat.float().contiguous()
+        _lib.require_gpu(feat, what="regroup_pyramid")
+        dst = torch.empty(B * T * groups, N, H, W, C, device=feat.device, dtype=out_dtype)
+        code = _lib.RAC_F32 if out_dtype == torch.float32 else _lib.RAC_BF16
+        rc = _lib.lib().rac_regroup_fwd(_lib.ptr(feat), _lib.ptr(dst), B, T, N, groups, C, H, W, code,
+                                        _lib.stream_ptr())
+        _lib.check(rc, "rac_regroup_fwd")
+        out.append(dst)
+    return out
+
+
+class RaCFormerTransformerDecoder(nn.Module):
+    """racformer_transformer.py:61-142"""
+
+    def __init__(self, embed_dims, num_frames=8, num_points=4, num_points_bev=4, num_layers=6, num_levels=4,
+                 num_classes=10, code_size=10, img_depth_num=3, bev_depth_num=5, pc_range=[], num_ray=150,
+                 d_region_list=[0.15, 0.1, 0.1, 0.08, 0.08, 0.05], spatial_shapes=(128, 128), init_cfg=None,
+                 num_cams=6):
+        super().__init__()
+        self.num_layers, self.pc_range, self.num_cams = num_layers, pc_range, num_cams
+        # params are shared across all decoder layers (racformer_transformer.py:84-89)
+        self.decoder_layer = RaCFormerTransformerDecoderLayer(
+            embed_dims, num_frames, num_points, num_points_bev, num_levels, num_classes, code_size,
+            img_depth_num=img_depth_num, bev_depth_num=bev_depth_num, num_ray=num_ray, pc_range=pc_range,
+            d_region_list=d_region_list, spatial_shapes=spatial_shapes)
+        self.feature_dtype = torch.float32
+
+    @torch.no_grad()
+    def init_weights(self):
+        self.decoder_layer.init_weights()
+
+    def stage_metas(self, img_metas, B, device):
+        """Host-side numerics of :99-109 (float64 timestamps -> float32 time_diff; lidar2img),
+        one upload each; also the clamped divisor of :266-269."""
+        ts = np.array([m["img_timestamp"] for m in img_metas], dtype=np.float64)
+        ts = np.reshape(ts, [B, -1, self.num_cams])
+        td = np.mean(ts[:, :1, :] - ts, axis=-1).astype(np.float32)
+        td_safe = td.copy()
+        td_safe[td_safe < 1e-5] = 1.0
+        l2i = np.asarray([m["lidar2img"] for m in img_metas]).astype(np.float32)
+        img_metas[0]["time_diff"] = torch.from_numpy(td).to(device)
+        img_metas[0]["time_diff_safe"] = torch.from_numpy(td_safe).to(device)
+        img_metas[0]["lidar2img"] = torch.from_numpy(l2i).to(device)
+
+    def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
+                stages_per_layer=None):
+        self.stage_metas(img_metas, query_bbox.shape[0], query_bbox.device)
+        grouped = regroup_pyramid(mlvl_feats, self.num_cams, 4, self.feature_dtype)
+        for lvl, g in enumerate(grouped):
+            mlvl_feats[lvl] = g  # the reference mutates the caller's list too (:124)
+        prepared = self.decoder_layer.prepare(lss_bev_feats, radar_bev_feats)
+        cls_scores, bbox_preds = [], []
+        for i in range(self.num_layers):
+            st = {} if stages_per_layer is not None else None
+            query_feat, cls_score, bbox_pred = self.decoder_layer(
+                query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
+                layer=i, prepared=prepared, stages=st)
+            if stages_per_layer is not None:
+                stages_per_layer.append(st)
+            query_bbox = bbox_pred.detach()
+            cls_scores.append(cls_score)
+            bbox_preds.append(theta_d2xy_coods(bbox_pred))
+        return torch.stack(cls_scores), torch.stack(bbox_preds)
+
+
+@_register
+class RaCFormerTransformer(nn.Module):
+    """racformer_transformer.py:17-58"""
+
+    def __init__(self, embed_dims, num_frames=8, num_points=4, num_points_bev=4, num_layers=6, num_levels=4,
+                 num_classes=10, code_size=10, img_depth_num=3, bev_depth_num=5, pc_range=[], num_ray=150,
+                 d_region_list=[0.15, 0.1, 0.1, 0.08, 0.08, 0.05], spatial_shapes=(128, 128), init_cfg=None,
+                 num_cams=6):
+        assert init_cfg is None, "To prevent abnormal initialization behavior, init_cfg is not allowed to be set"
+        super().__init__()
+        self.embed_dims, self.pc_range, self.num_cams = embed_dims, pc_range, num_cams
+        self.decoder = RaCFormerTransformerDecoder(
+            embed_dims, num_frames, num_points, num_points_bev, num_layers, num_levels, num_classes, code_size,
+            img_depth_num=img_depth_num, bev_depth_num=bev_depth_num, pc_range=pc_range, num_ray=num_ray,
+            d_region_list=d_region_list, spatial_shapes=spatial_shapes, num_cams=num_cams)
+
+    @torch.no_grad()
+    def init_weights(self):
+        self.decoder.init_weights()
+
+    def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
+                stages_per_layer=None):
+        cls_scores, bbox_preds = self.decoder(query_bbox, query_feat, mlvl_feats, lss_bev_feats,
+                                              radar_bev_feats, attn_mask, img_metas, stages_per_layer)
+        return torch.nan_to_num(cls_scores), torch.nan_to_num(bbox_preds)

@@ -42,8 +42,24 @@ def build_head(cfg, device, feature_dtype=torch.float32):
     syn.fill_params(head.transformer, 0)
     with torch.no_grad():
         head.label_enc.weight.copy_(torch.from_numpy(syn.rng_normal(77, tuple(head.label_enc.weight.shape), 0.1)))
+        # a trained head's query embedding is a tame polar grid; nn.Embedding's N(0,1) default would put
+        # e^N(0,1)-sized boxes and random yaw in every query (see racformer_amd/synthetic.py)
+        head.init_query_bbox.weight.copy_(syn.make_queries(cfg, 0)[0][0])
     head.transformer.decoder.feature_dtype = feature_dtype
     return head.eval().to(device)
+
+
+def host_threads():
+    """Threads the CPU baseline may use: the cgroup CPU quota of this box (the GPU pool gives a
+    1-GPU job about 16 cores of a 256-core host), never the raw core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
 
 
 def msmv_algorithmic_bytes(loc, feat_shapes, elt_bytes, out_elems):
@@ -94,7 +110,8 @@ def main():
 
     def step():
         with torch.no_grad():
-            preds = head(list(pyramid), lss, radar, metas)
+            fresh = [dict(m) for m in metas]                # new sample -> metas are staged (H2D) again
+            preds = head(list(pyramid), lss, radar, fresh)
             det = head.get_detections_fixed(preds)          # [1,300,11]
             return dp.all_gather_detections(det)            # [world,1,300,11]
 
@@ -165,7 +182,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import restate as R  # the checker, timed as the reported CPU baseline only
-        torch.set_num_threads(os.cpu_count())
+        torch.set_num_threads(host_threads())
         sd = {k: v.detach().cpu() for k, v in head.transformer.state_dict().items()}
         hsd = {k: v.detach().cpu() for k, v in head.state_dict().items() if not k.startswith("transformer.")}
         cpu_pyr = [f.cpu() for f in pyramid]
@@ -175,7 +192,7 @@ def main():
             cpu_s = time.perf_counter() - c0
         # parity of the benchmarked step against the oracle, reported beside the numbers
         with torch.no_grad():
-            preds = head(list(pyramid), lss, radar, metas)
+            preds = head(list(pyramid), lss, radar, [dict(m) for m in metas])
         eb = (preds["all_bbox_preds"].cpu() - ref["all_bbox_preds"]).abs().amax(-1)
         mism = int((preds["all_cls_scores"].cpu().argmax(-1) != ref["all_cls_scores"].argmax(-1)).sum())
         result["cpu_baseline"] = {

@@ -164,11 +164,13 @@ extern "C" int rac_msda_fwd(const void *value, const int64_t *shapes, const int6
                             const float *loc, const float *attn, float *out, int bs, int keys,
                             int heads, int dim, int Q, int L, int P, int dtype, void *stream)
 {
-    RAC_CHECK_ARG(value && shapes && starts && loc && attn && out, "rac_msda_fwd: null pointer");
     RAC_CHECK_ARG(L >= 1 && L <= RAC_MAX_LEVELS, "rac_msda_fwd: L=%d out of [1,%d]", L, RAC_MAX_LEVELS);
     RAC_CHECK_ARG(bs >= 0 && Q >= 0 && heads >= 1 && dim >= 1 && keys >= 0 && P >= 0,
                   "rac_msda_fwd: bad sizes bs=%d keys=%d heads=%d dim=%d Q=%d P=%d", bs, keys, heads, dim, Q, P);
     RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_msda_fwd: dtype %d", dtype);
+    if (bs == 0 || Q == 0)
+        return 0;
+    RAC_CHECK_ARG(value && shapes && starts && loc && attn && out, "rac_msda_fwd: null pointer");
     MsdaArgs a;
     for (int l = 0; l < RAC_MAX_LEVELS; ++l) {
         a.H[l] = a.W[l] = 1;
@@ -185,8 +187,6 @@ extern "C" int rac_msda_fwd(const void *value, const int64_t *shapes, const int6
     a.value = value; a.loc = loc; a.attn = attn; a.out = out;
     a.bs = bs; a.keys = keys; a.heads = heads; a.dim = dim; a.Q = Q; a.L = L; a.P = P;
     a.blocks_per_b = (Q * heads + MSDA_ITEMS - 1) / MSDA_ITEMS;
-    if (bs == 0 || Q == 0)
-        return 0;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)MSDA_ITEMS * L * P * 3 * sizeof(float);
     if (dim == 64 && P >= 1 && lds <= 48 * 1024) {

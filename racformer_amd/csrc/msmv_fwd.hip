@@ -214,10 +214,12 @@ extern "C" int rac_msmv_fwd(const void *const *feats, const int32_t *hw, int L, 
                             const float *w, float *out, int S, int N, int Q, int P, int C, int dtype,
                             int out_layout, int T, int G, void *stream)
 {
-    RAC_CHECK_ARG(feats && hw && loc && w && out, "rac_msmv_fwd: null pointer");
     RAC_CHECK_ARG(L >= 1 && L <= RAC_MAX_LEVELS, "rac_msmv_fwd: L=%d out of [1,%d]", L, RAC_MAX_LEVELS);
     RAC_CHECK_ARG(S >= 0 && Q >= 0 && N >= 1 && C >= 1, "rac_msmv_fwd: bad sizes S=%d N=%d Q=%d C=%d", S, N, Q, C);
     RAC_CHECK_ARG(P >= 0 && P <= RAC_MAX_POINTS, "rac_msmv_fwd: num_point exceed limits (P=%d > %d)", P, RAC_MAX_POINTS);
+    if (S == 0 || Q == 0 || P == 0)
+        return 0;  // empty output: nothing to launch (torch hands out null data pointers for empty tensors)
+    RAC_CHECK_ARG(feats && hw && loc && w && out, "rac_msmv_fwd: null pointer");
     RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_msmv_fwd: dtype %d", dtype);
     RAC_CHECK_ARG(out_layout == RAC_OUT_SQCP || out_layout == RAC_OUT_BQGTPC, "rac_msmv_fwd: layout %d", out_layout);
     if (out_layout == RAC_OUT_BQGTPC)
@@ -239,8 +241,6 @@ extern "C" int rac_msmv_fwd(const void *const *feats, const int32_t *hw, int L, 
     a.T = out_layout == RAC_OUT_BQGTPC ? T : 0;
     a.G = out_layout == RAC_OUT_BQGTPC ? G : 1;
     a.blocks_per_slot = (Q + MSMV_ROWS - 1) / MSMV_ROWS;
-    if (S == 0 || Q == 0 || P == 0)
-        return 0;
     hipStream_t st = (hipStream_t)stream;
     int fell_through = 1;
     if (C == 64 && (L == 2 || L == 4 || L == 5)) {

@@ -51,7 +51,7 @@ def test_argument_errors_need_no_gpu(built_lib):
     """Argument validation happens before any HIP call: exercised here without a GPU."""
     from racformer_amd import _lib
     lib = _lib.lib()
-    rc = lib.rac_msmv_fwd(None, None, 4, None, None, None, 1, 1, 1, 1, 64, 0, 0, 1, 1, None)
+    rc = lib.rac_msmv_fwd(None, None, 4, None, None, None, 1, 1, 1, 1, 64, 0, 0, 1, 1, None)  # non-empty sizes
     assert rc == -1 and b"null pointer" in lib.rac_last_error()
     one = (ctypes.c_void_p * 1)(1)
     hw = (ctypes.c_int32 * 2)(4, 4)

@@ -107,6 +107,6 @@ def test_decoder_f8(golden_dir, name, cfg):
     """Full f8 shapes (about 15 s of CPU each): north_star tolerance -- box regressions within
     1e-3, class argmax bit-exact -- for the oracle against the reference CPU forward."""
     g = load(golden_dir, name)
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(16, os.cpu_count()))
     cls, box = _run_decoder(cfg, g)
     decoder_parity(cls, box, g["cls"], g["box"], what=name)

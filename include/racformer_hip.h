@@ -18,6 +18,10 @@
  *                        models/multi_scale_deformable_attn_function.py:118-124
  *   rac_regroup_fwd   <- the channel-last regroup in RaCFormerTransformerDecoder.forward,
  *                        models/racformer_transformer.py:112-124
+ *   rac_sampling4d_fwd<- RaCFormerSampling.inner_forward + sampling_4d + msmv op, fused
+ *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
+ *   rac_bev_sampling_fwd <- BEVSampling keypoints + BEVSelfAttention's MSDA + frame fusion, fused
+ *                        models/racformer_transformer.py:490-529, models/bev_self_attention.py:176-213
  */
 #ifndef RACFORMER_HIP_H
 #define RACFORMER_HIP_H
@@ -73,6 +77,41 @@ int rac_msda_fwd(const void *value, const int64_t *shapes, const int64_t *starts
 /* Pyramid regroup: in [B, T*N, G*C, H, W] f32 -> out [B*T*G, N, H, W, C] (dtype out_dtype). */
 int rac_regroup_fwd(const float *in, void *out, int B, int T, int N, int G, int C, int H, int W,
                     int out_dtype, void *stream);
+
+/* Adaptive 4D sampling of one decoder layer, fully fused (keypoints -> projection -> first-valid-view
+ * -> multi-scale gather).  Replaces RaCFormerSampling.inner_forward + sampling_4d + the msmv op
+ * (models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134).
+ *   feats[l]     : device [B*T*G, N, H_l, W_l, 64] (dtype), hw HOST L x (H,W)
+ *   query_bbox   : device f32 [B,Q,10] polar boxes (theta, d, z, log w, log l, log h, sin, cos, vx, vy)
+ *   offsets      : device f32, row (b,q) at offsets + (b*Q+q)*ld_off, G*NP*D*3 values (sampling_offset Linear)
+ *   ray_logits   : device f32, rows of D values, stride ld_ray          (ray_points_offset Linear)
+ *   scale_logits : device f32, rows of G*T*NP*D*L values, stride ld_scale (scale_weights Linear, softmax over L here)
+ *   time_diff    : device f32 [B,T];  lidar2img: device f32 [B,T*N,4,4]
+ *   out          : device f32 [B,Q,G,T*NP*D,64]
+ *   loc_out,w_out: optional debug outputs [S,Q,P,3] (u,v,view/(N-1)) and [S,Q,P,L] (NULL,NULL to skip)
+ *   pc_range (6), depth_base (D = torch.linspace(-d_region,d_region,D)): HOST pointers */
+int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox,
+                       const float *offsets, const float *ray_logits, const float *scale_logits,
+                       const float *time_diff, const float *lidar2img, float *out, float *loc_out,
+                       float *w_out, int ld_off, int ld_ray, int ld_scale, int B, int T, int N, int G, int Q,
+                       int NP, int D, int C, const float *pc_range, const float *depth_base, float d_region,
+                       float image_h, float image_w, float eps, int dtype, void *stream);
+
+/* BEV deformable cross-attention of one decoder layer, fully fused (keypoints -> per-frame
+ * deformable attention -> softmax-over-frames fusion).  Replaces BEVSampling.inner_forward's keypoint
+ * chain, the MSDA op and the frame fusion (models/racformer_transformer.py:490-529,
+ * models/bev_self_attention.py:176-213); output_proj + identity stay outside.
+ *   value        : device [B*T, H*W, heads, 64] (dtype) -- hoisted value_proj(bev + pos)
+ *   offsets      : rows of heads*NP*D*2 values (stride ld_off); ray_logits rows of D (ld_ray);
+ *   scale_logits : rows of heads*NP*D (ld_scale, softmax over the NP*D points of a head here);
+ *   queue_logits : rows of T (ld_queue, softmax over frames here)
+ *   out          : device f32 [B,Q,heads*64];  loc_out: optional [B,Q,heads,T,NP*D,2] or NULL */
+int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float *offsets,
+                         const float *ray_logits, const float *scale_logits, const float *queue_logits,
+                         const float *time_diff, float *out, float *loc_out, int ld_off, int ld_ray,
+                         int ld_scale, int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W,
+                         int dim, const float *pc_range, const float *depth_base, float d_region, int dtype,
+                         void *stream);
 
 #ifdef __cplusplus
 }

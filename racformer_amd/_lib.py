@@ -15,13 +15,15 @@ OUT_SQCP, OUT_BQGTPC = 0, 1
 _lib = None
 
 # name -> (restype, argtypes); must list every symbol include/racformer_hip.h declares
-_vp, _i = ctypes.c_void_p, ctypes.c_int
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 SIGNATURES = {
     "rac_abi_version": (_i, []),
     "rac_last_error": (ctypes.c_char_p, []),
     "rac_msmv_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rac_msda_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rac_regroup_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rac_sampling4d_fwd": (_i, [_vp, _vp, _i] + [_vp] * 9 + [_i] * 3 + [_i] * 8 + [_vp, _vp] + [_f] * 5 + [_i, _vp]),
+    "rac_bev_sampling_fwd": (_i, [_vp] * 9 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
 }
 
 

@@ -1,0 +1,288 @@
+// sampling_fused.hip -- adaptive 4D sampling as ONE kernel, for gfx950 (MI355X).
+//
+// Fuses, per decoder layer, what the reference runs as ~60 elementwise torch kernels, a
+// broadcast-expanded [B,T,N,Q,GP,4,4] matmul, two permute copies and the msmv gather:
+//   RaCFormerSampling.inner_forward  models/racformer_transformer.py:361-408  (keypoints)
+//   sampling_4d                      models/sparsebev_sampling.py:45-131      (projection, validity,
+//                                    first-valid-view selection, slot regroup, output regroup)
+//   msmv op                          models/csrc/msmv_sampling/msmv_sampling_forward.cu:75-164
+// Inputs are the three Linear outputs of the sampling module (offsets, ray-depth logits, scale
+// logits), the query boxes, time_diff and lidar2img; output is [B,Q,G,T*P,C] (what sampling_4d
+// returns).  Nothing else touches HBM: locations and softmaxed scale weights live in LDS only
+// (optionally also written out for parity debugging, the counterpart of the reference's DUMP
+// hooks, sparsebev_sampling.py:83-87).
+//
+// Workgroup = 4 waves = 4 consecutive queries of one slot (b,t,g).  Phase 1: the first 4*P threads
+// compute one keypoint each (box decode, offset, yaw rotation, velocity warp, polar jitter,
+// projection into the N cameras of frame t, first valid view, softmax over levels) into LDS.
+// Phase 2: identical to msmv_fwd_c64_kernel -- 16-lane group per point, 16-byte loads, 16 taps in
+// flight, XCD-aware slot mapping, 1 KiB coalesced stores.
+//
+// Index conventions reproduced from the reference: point p of a group = (num_point, depth) with
+// depth fastest (:394); slot s = (b*T+t)*G+g for points/features/outputs, but the scale weights of
+// slot s are read from the (b,g',t') flattening at s' = t*G+g, g' = s'/T, t' = s'%T
+// (sparsebev_sampling.py:113-120, quirk Q1).
+#include "rac_common.h"
+
+#define S4D_ROWS 4
+#define S4D_MAX_DEPTH 16
+#define S4D_MAX_CAMS 16
+
+struct S4dArgs {
+    const void *feat[RAC_MAX_LEVELS];
+    int H[RAC_MAX_LEVELS];
+    int W[RAC_MAX_LEVELS];
+    const float *qbox;       // [B,Q,10]
+    const float *off;        // [B,Q,G*P*3]
+    const float *ray;        // [B,Q,D]
+    const float *scale;      // [B,Q,G,T,P,L] logits
+    const float *time_diff;  // [B,T]
+    const float *l2i;        // [B,T*N,16]
+    float *out;              // [B,Q,G,T*P,C]
+    float *loc_out;          // optional [S,Q,P,3]
+    float *w_out;            // optional [S,Q,P,L]
+    float depth_base[S4D_MAX_DEPTH];
+    float pc[6];
+    float d_region, image_h, image_w, eps;
+    int L, B, T, N, G, Q, NP, D, P;
+    int ld_off, ld_ray, ld_scale;  // row strides (floats) of off / ray / scale: slices of one fused GEMM output
+    int blocks_per_slot;
+};
+
+#define S4D_TWO_PI 6.283185307179586f
+
+template <int L>
+__device__ __forceinline__ void s4d_keypoint(const S4dArgs &a, const float *sl2i, int b, int t, int g, int q,
+                                             int p, float *loc3, float *wl)
+{
+    const float *qb = a.qbox + ((size_t)b * a.Q + q) * 10;
+    const float sx = a.pc[3] - a.pc[0], sy = a.pc[4] - a.pc[1], sz = a.pc[5] - a.pc[2];
+    // theta_d2xy (clamped) + decode_bbox
+    const float ang0 = qb[0] * S4D_TWO_PI;
+    const float rad0 = qb[1] * 65.0f;
+    const float xn0 = fminf(fmaxf((51.2f + rad0 * cosf(ang0)) / 102.4f, 0.f), 1.f);
+    const float yn0 = fminf(fmaxf((51.2f + rad0 * sinf(ang0)) / 102.4f, 0.f), 1.f);
+    const float cx = xn0 * sx + a.pc[0], cy = yn0 * sy + a.pc[1], cz = qb[2] * sz + a.pc[2];
+    const float yaw = atan2f(qb[6], qb[7]);
+    const float cs = cosf(yaw), sn = sinf(yaw);
+    // make_sample_points: xyz + R_z(yaw) (wlh * offset)
+    const float *o = a.off + ((size_t)b * a.Q + q) * a.ld_off + ((size_t)g * a.P + p) * 3;
+    const float dx = expf(qb[3]) * o[0], dy = expf(qb[4]) * o[1], dz = expf(qb[5]) * o[2];
+    float px = cx + (dx * cs - dy * sn);
+    float py = cy + (dx * sn + dy * cs);
+    const float pz = cz + dz;
+    // velocity warp to frame t
+    const float td = a.time_diff[b * a.T + t];
+    px -= qb[8] * td;
+    py -= qb[9] * td;
+    // normalise, to polar, jitter the range, back to metric
+    const float nx = (px - a.pc[0]) / sx, ny = (py - a.pc[1]) / sy;
+    const float ex = nx * 102.4f - 51.2f, ey = ny * 102.4f - 51.2f;
+    float dist = sqrtf(ex * ex + ey * ey) / 65.0f;
+    float th = fmodf(atan2f(ey, ex) + S4D_TWO_PI, S4D_TWO_PI) / S4D_TWO_PI;
+    const int dd = p % a.D;
+    const float sg = 1.f / (1.f + expf(-a.ray[((size_t)b * a.Q + q) * a.ld_ray + dd]));
+    dist += a.depth_base[dd] + (sg * 2.f - 1.f) * a.d_region / (float)a.D / 2.f;
+    const float ang = th * S4D_TWO_PI, rad = dist * 65.0f;
+    const float X = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f) * sx + a.pc[0];
+    const float Y = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f) * sy + a.pc[1];
+    // project into the N cameras of frame t; first valid view (0 if none)
+    float u_sel = 0.f, v_sel = 0.f;
+    int view = 0;
+    bool found = false;
+    for (int n = 0; n < a.N; ++n) {
+        const float *m = sl2i + n * 16;
+        const float camx = m[0] * X + m[1] * Y + m[2] * pz + m[3];
+        const float camy = m[4] * X + m[5] * Y + m[6] * pz + m[7];
+        const float homo = m[8] * X + m[9] * Y + m[10] * pz + m[11];
+        const float hz = fmaxf(homo, a.eps);
+        const float u = camx / hz / a.image_w;
+        const float v = camy / hz / a.image_h;
+        const bool valid = homo > a.eps && v > 0.f && v < 1.f && u > 0.f && u < 1.f;
+        if (n == 0 || (valid && !found)) {
+            u_sel = u;
+            v_sel = v;
+            view = n;
+        }
+        found = found || valid;
+    }
+    loc3[0] = u_sel;
+    loc3[1] = v_sel;
+    loc3[2] = (float)view;  // integer view index (the reference stores view/(N-1) and rounds it back)
+    // softmax over levels of the (b, g', t') weight slot
+    const int sp = t * a.G + g;
+    const int gq = sp / a.T, tq = sp % a.T;
+    const float *lg = a.scale + ((size_t)b * a.Q + q) * a.ld_scale + ((((size_t)gq * a.T + tq) * a.P + p)) * L;
+    float mx = lg[0];
+#pragma unroll
+    for (int l = 1; l < L; ++l)
+        mx = fmaxf(mx, lg[l]);
+    float e[L], sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        e[l] = expf(lg[l] - mx);
+        sum += e[l];
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+        wl[l] = e[l] / sum;
+}
+
+template <typename FT>
+__device__ __forceinline__ rac_f4 s4d_tap(const FT *base, int h, int w, int W, bool ok)
+{
+    rac_f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok)
+        v = rac_ld4(base + ((size_t)h * W + w) * 64);
+    return v;
+}
+
+template <typename FT, int L>
+__global__ __launch_bounds__(256) void sampling4d_c64_kernel(const S4dArgs a)
+{
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, sub = lane >> 4, c4 = lane & 15;
+    const int P = a.P;
+
+    const int S = a.B * a.T * a.G;
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int s = xcd + 8 * (j / a.blocks_per_slot);
+    if (s >= S)
+        return;
+    const int q0 = (j % a.blocks_per_slot) * S4D_ROWS;
+    const int nrows = min(S4D_ROWS, a.Q - q0);
+    const int g = s % a.G, t = (s / a.G) % a.T, b = s / (a.G * a.T);
+
+    float *sloc = smem;                     // [rows][P][3]
+    float *sw = sloc + S4D_ROWS * P * 3;    // [rows][P][L]
+    float *sl2i = sw + S4D_ROWS * P * L;    // [N][16]
+    for (int i = tid; i < a.N * 16; i += 256)
+        sl2i[i] = a.l2i[((size_t)b * a.T + t) * a.N * 16 + i];
+    __syncthreads();
+    for (int i = tid; i < nrows * P; i += 256) {
+        const int r = i / P, p = i - r * P;
+        s4d_keypoint<L>(a, sl2i, b, t, g, q0 + r, p, sloc + i * 3, sw + i * L);
+        if (a.loc_out) {
+            float *lo = a.loc_out + (((size_t)s * a.Q + q0 + r) * P + p) * 3;
+            lo[0] = sloc[i * 3];
+            lo[1] = sloc[i * 3 + 1];
+            lo[2] = sloc[i * 3 + 2] / (float)max(a.N - 1, 1);
+            float *wo = a.w_out + (((size_t)s * a.Q + q0 + r) * P + p) * L;
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                wo[l] = sw[i * L + l];
+        }
+    }
+    __syncthreads();
+    if (wave >= nrows)
+        return;
+    const int q = q0 + wave;
+    const size_t out_row = ((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * (size_t)P * 64;
+
+    for (int p0 = 0; p0 < P; p0 += 4) {
+        const int p = p0 + sub;
+        const bool act = p < P;
+        const int pp = act ? p : P - 1;
+        const float *lp = sloc + (wave * P + pp) * 3;
+        const float *wp = sw + (wave * P + pp) * L;
+        const float lu = lp[0], lv = lp[1];
+        const int view = (int)lp[2];
+
+        rac_f4 v[L][4];
+        float tw[L][4];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int H = a.H[l], W = a.W[l];
+            const float h_im = lv * (float)(H - 1);
+            const float w_im = lu * (float)(W - 1);
+            const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const FT *base = (const FT *)a.feat[l] + ((size_t)s * a.N + view) * H * W * 64 + c4 * 4;
+            const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
+            const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+            v[l][0] = s4d_tap(base, h_low, w_low, W, t_ok && l_ok);
+            v[l][1] = s4d_tap(base, h_low, w_high, W, t_ok && r_ok);
+            v[l][2] = s4d_tap(base, h_high, w_low, W, b_ok && l_ok);
+            v[l][3] = s4d_tap(base, h_high, w_high, W, b_ok && r_ok);
+            tw[l][0] = hh * hw;
+            tw[l][1] = hh * lw;
+            tw[l][2] = lh * hw;
+            tw[l][3] = lh * lw;
+        }
+        rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float wl = wp[l];
+            acc.x += (tw[l][0] * v[l][0].x + tw[l][1] * v[l][1].x + tw[l][2] * v[l][2].x + tw[l][3] * v[l][3].x) * wl;
+            acc.y += (tw[l][0] * v[l][0].y + tw[l][1] * v[l][1].y + tw[l][2] * v[l][2].y + tw[l][3] * v[l][3].y) * wl;
+            acc.z += (tw[l][0] * v[l][0].z + tw[l][1] * v[l][1].z + tw[l][2] * v[l][2].z + tw[l][3] * v[l][3].z) * wl;
+            acc.w += (tw[l][0] * v[l][0].w + tw[l][1] * v[l][1].w + tw[l][2] * v[l][2].w + tw[l][3] * v[l][3].w) * wl;
+        }
+        if (act)
+            *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = acc;
+    }
+}
+
+extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox,
+                                  const float *offsets, const float *ray_logits, const float *scale_logits,
+                                  const float *time_diff, const float *lidar2img, float *out, float *loc_out,
+                                  float *w_out, int ld_off, int ld_ray, int ld_scale, int B, int T, int N, int G, int Q, int NP,
+                                  int D, int C,
+                                  const float *pc_range, const float *depth_base, float d_region, float image_h,
+                                  float image_w, float eps, int dtype, void *stream)
+{
+    RAC_CHECK_ARG(L == 2 || L == 4 || L == 5, "rac_sampling4d_fwd: L=%d (supported: 2, 4, 5)", L);
+    RAC_CHECK_ARG(C == 64, "rac_sampling4d_fwd: C=%d (the fused kernel is built for 64 channels per group)", C);
+    RAC_CHECK_ARG(B >= 0 && Q >= 0 && T >= 1 && N >= 1 && N <= S4D_MAX_CAMS && G >= 1 && NP >= 1 && D >= 1 &&
+                      D <= S4D_MAX_DEPTH,
+                  "rac_sampling4d_fwd: bad sizes B=%d T=%d N=%d G=%d Q=%d NP=%d D=%d", B, T, N, G, Q, NP, D);
+    const int P = NP * D;
+    RAC_CHECK_ARG(P <= RAC_MAX_POINTS, "rac_sampling4d_fwd: num_point exceed limits (P=%d > %d)", P, RAC_MAX_POINTS);
+    RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_sampling4d_fwd: dtype %d", dtype);
+    if (B == 0 || Q == 0)
+        return 0;
+    RAC_CHECK_ARG(feats && hw && query_bbox && offsets && ray_logits && scale_logits && time_diff && lidar2img &&
+                      out && pc_range && depth_base,
+                  "rac_sampling4d_fwd: null pointer");
+    RAC_CHECK_ARG((loc_out == nullptr) == (w_out == nullptr), "rac_sampling4d_fwd: loc_out and w_out go together");
+    RAC_CHECK_ARG(ld_off >= G * NP * D * 3 && ld_ray >= D && ld_scale >= G * T * NP * D * L, "rac_sampling4d_fwd: row strides too small");
+    S4dArgs a;
+    for (int l = 0; l < RAC_MAX_LEVELS; ++l) {
+        a.feat[l] = nullptr;
+        a.H[l] = a.W[l] = 1;
+    }
+    for (int l = 0; l < L; ++l) {
+        RAC_CHECK_ARG(feats[l] != nullptr && hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "rac_sampling4d_fwd: level %d", l);
+        a.feat[l] = feats[l];
+        a.H[l] = hw[2 * l];
+        a.W[l] = hw[2 * l + 1];
+    }
+    a.qbox = query_bbox; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
+    a.time_diff = time_diff; a.l2i = lidar2img; a.out = out; a.loc_out = loc_out; a.w_out = w_out;
+    for (int i = 0; i < S4D_MAX_DEPTH; ++i)
+        a.depth_base[i] = i < D ? depth_base[i] : 0.f;
+    for (int i = 0; i < 6; ++i)
+        a.pc[i] = pc_range[i];
+    a.d_region = d_region; a.image_h = image_h; a.image_w = image_w; a.eps = eps;
+    a.L = L; a.B = B; a.T = T; a.N = N; a.G = G; a.Q = Q; a.NP = NP; a.D = D; a.P = P;
+    a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale;
+    a.blocks_per_slot = (Q + S4D_ROWS - 1) / S4D_ROWS;
+    const int S = B * T * G;
+    const int nb = 8 * ((S + 7) / 8) * a.blocks_per_slot;
+    const size_t lds = ((size_t)S4D_ROWS * P * (3 + L) + (size_t)N * 16) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define S4D_LAUNCH(FT, LL) hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL>), dim3(nb), dim3(256), lds, st, a)
+    if (dtype == RAC_F32) {
+        if (L == 2) S4D_LAUNCH(float, 2); else if (L == 4) S4D_LAUNCH(float, 4); else S4D_LAUNCH(float, 5);
+    } else {
+        if (L == 2) S4D_LAUNCH(unsigned short, 2); else if (L == 4) S4D_LAUNCH(unsigned short, 4); else S4D_LAUNCH(unsigned short, 5);
+    }
+#undef S4D_LAUNCH
+    return rac_launch_status("rac_sampling4d_fwd");
+}

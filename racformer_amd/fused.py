@@ -1,0 +1,95 @@
+"""Python launchers of the two fully fused per-layer kernels (C-ABI: rac_sampling4d_fwd,
+rac_bev_sampling_fwd).  The Linear outputs they consume may be column slices of one wide GEMM
+output: only the last dimension has to be contiguous, the row stride is passed through."""
+import ctypes
+import functools
+
+import torch
+
+from . import _lib
+
+
+@functools.lru_cache(maxsize=64)
+def _depth_base(d_region, depth_num):
+    """torch.linspace(-d_region, d_region, depth_num) as the reference evaluates it
+    (racformer_transformer.py:395,515), computed once per (layer, depth_num) on the host."""
+    vals = torch.linspace(-d_region, d_region, depth_num).tolist()
+    return (ctypes.c_float * depth_num)(*vals)
+
+
+def _rows(t, width, what):
+    """[B,Q,width] view with unit last stride -> (pointer, row stride in floats)."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError(f"racformer_amd.{what}: expected a float32 CUDA tensor")
+    if t.shape[-1] != width or t.stride(-1) != 1 or (t.dim() == 3 and t.stride(0) != t.shape[1] * t.stride(1)):
+        raise RuntimeError(f"racformer_amd.{what}: expected [B,Q,{width}] rows with unit inner stride")
+    return _lib.ptr(t), int(t.stride(-2))
+
+
+def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, time_diff, lidar2img,
+                     num_frames, num_groups, num_points, depth_num, pc_range, d_region, image_h, image_w,
+                     eps=1e-5, debug=False):
+    """-> [B,Q,G,T*P,C] (and, with debug=True, the kernel's own locations [S,Q,P,3] and softmaxed scale
+    weights [S,Q,P,L] for parity checks)."""
+    feats = list(mlvl_feats)
+    L = len(feats)
+    _lib.require_gpu(*feats, query_bbox, time_diff, lidar2img, what="sampling4d_fused")
+    B, Q, _ = query_bbox.shape
+    T, G, NP, D = num_frames, num_groups, num_points, depth_num
+    P = NP * D
+    S, N, _, _, C = feats[0].shape
+    if S != B * T * G or lidar2img.shape[1] != T * N:
+        raise RuntimeError("sampling4d_fused: feature slots / lidar2img do not match B*T*G / T*N")
+    p_off, ld_off = _rows(offsets, G * P * 3, "sampling4d_fused(offsets)")
+    p_ray, ld_ray = _rows(ray_logits, D, "sampling4d_fused(ray_logits)")
+    p_sc, ld_sc = _rows(scale_logits, G * T * P * L, "sampling4d_fused(scale_logits)")
+    out = torch.empty(B, Q, G, T * P, C, device=query_bbox.device, dtype=torch.float32)
+    loc_out = w_out = None
+    if debug:
+        loc_out = torch.empty(S, Q, P, 3, device=out.device, dtype=torch.float32)
+        w_out = torch.empty(S, Q, P, L, device=out.device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    hw = (ctypes.c_int32 * (2 * L))(*[int(x) for f in feats for x in f.shape[2:4]])
+    pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    ev = _lib.timer.record("sampling4d_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_sampling4d_fwd(
+        ptrs, hw, L, _lib.ptr(query_bbox), p_off, p_ray, p_sc, _lib.ptr(time_diff), _lib.ptr(lidar2img),
+        _lib.ptr(out), _lib.ptr(loc_out) if debug else None, _lib.ptr(w_out) if debug else None,
+        ld_off, ld_ray, ld_sc, B, T, N, G, Q, NP, D, C, pc, _depth_base(float(d_region), D), float(d_region),
+        float(image_h), float(image_w), float(eps), _lib.dtype_code(feats[0]), _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_sampling4d_fwd")
+    return (out, loc_out, w_out) if debug else out
+
+
+def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits, queue_logits, time_diff,
+                       num_frames, num_heads, num_points, depth_num, pc_range, d_region, debug=False):
+    """value [B*T, H*W, heads, 64] -> [B,Q,heads*64] (frame-fused, before output_proj)."""
+    _lib.require_gpu(value, query_bbox, time_diff, what="bev_sampling_fused")
+    B, Q, _ = query_bbox.shape
+    T, Hn, NP, D = num_frames, num_heads, num_points, depth_num
+    P = NP * D
+    H, W = hw
+    if tuple(value.shape) != (B * T, H * W, Hn, 64):
+        raise RuntimeError(f"bev_sampling_fused: value must be [{B * T},{H * W},{Hn},64], got {tuple(value.shape)}")
+    p_off, ld_off = _rows(offsets, Hn * P * 2, "bev_sampling_fused(offsets)")
+    p_ray, ld_ray = _rows(ray_logits, D, "bev_sampling_fused(ray_logits)")
+    p_sc, ld_sc = _rows(scale_logits, Hn * P, "bev_sampling_fused(scale_logits)")
+    p_qu, ld_qu = _rows(queue_logits, T, "bev_sampling_fused(queue_logits)")
+    out = torch.empty(B, Q, Hn * 64, device=query_bbox.device, dtype=torch.float32)
+    loc_out = torch.empty(B, Q, Hn, T, P, 2, device=out.device, dtype=torch.float32) if debug else None
+    pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    ev = _lib.timer.record("bev_sampling_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_bev_sampling_fwd(
+        _lib.ptr(value), _lib.ptr(query_bbox), p_off, p_ray, p_sc, p_qu, _lib.ptr(time_diff), _lib.ptr(out),
+        _lib.ptr(loc_out) if debug else None, ld_off, ld_ray, ld_sc, ld_qu, B, T, Q, Hn, NP, D, H, W, 64, pc,
+        _depth_base(float(d_region), D), float(d_region), _lib.dtype_code(value), _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_bev_sampling_fwd")
+    return (out, loc_out) if debug else out

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
+from .fused import bev_sampling_fused, sampling4d_fused
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -182,10 +183,23 @@ class RaCFormerSampling(nn.Module):
         sw = self.scale_weights(query_feat).view(B, Q, G, T, D * NP, L)
         return points, torch.softmax(sw, dim=-1)
 
-    def forward(self, query_ray, query_feat, mlvl_feats, img_metas, d_region=0.1):
+    def forward_unfused(self, query_ray, query_feat, mlvl_feats, img_metas, d_region=0.1):
+        """torch keypoint chain + sampling_4d on the msmv operator (the reference's decomposition)."""
         image_h, image_w, _ = img_metas[0]["img_shape"][0]
         points, sw = self.keypoints(query_ray, query_feat, img_metas[0]["time_diff"], d_region)
         return sampling_4d(points, mlvl_feats, sw, img_metas[0]["lidar2img"], image_h, image_w)
+
+    def forward(self, query_ray, query_feat, mlvl_feats, img_metas, d_region=0.1, linear_out=None, debug=False):
+        """One fused HIP kernel (rac_sampling4d_fwd).  ``linear_out`` = (offsets, ray logits, scale
+        logits) if the caller already ran the three Linears as part of a wider GEMM."""
+        image_h, image_w, _ = img_metas[0]["img_shape"][0]
+        if linear_out is None:
+            linear_out = (self.sampling_offset(query_feat), self.ray_points_offset(query_feat),
+                          self.scale_weights(query_feat))
+        off, ray, sc = linear_out
+        return sampling4d_fused(mlvl_feats, query_ray.contiguous(), off, ray, sc, img_metas[0]["time_diff"],
+                                img_metas[0]["lidar2img"], self.num_frames, self.num_groups, self.num_points,
+                                self.depth_num, self.pc_range, d_region, image_h, image_w, debug=debug)
 
 
 def sampling_4d(sample_points, mlvl_feats, scale_weights, lidar2img, image_h, image_w, aggregate=True,
@@ -391,9 +405,20 @@ class BEVSampling(nn.Module):
         sw = torch.softmax(sw, dim=-1).expand(B, Q, Hn, T, self.num_levels, D * NP).contiguous()
         return loc, sw
 
-    def attend_prepared(self, query_ray, query_feat, value, hw, time_diff, d_region):
+    def attend_prepared_unfused(self, query_ray, query_feat, value, hw, time_diff, d_region):
+        """torch keypoint chain + MSDA operator + torch frame fusion (the reference's decomposition)."""
         loc, sw = self.keypoints(query_ray, query_feat, time_diff, d_region)
         return self.attention.attend(query_feat, value, loc, sw, hw)
+
+    def attend_prepared(self, query_ray, query_feat, value, hw, time_diff, d_region, linear_out=None):
+        """One fused HIP kernel (rac_bev_sampling_fwd) + output_proj + identity."""
+        if linear_out is None:
+            linear_out = (self.sampling_offset(query_feat), self.ray_points_offset(query_feat),
+                          self.scale_weights(query_feat), self.attention.bev_queue_weight(query_feat))
+        off, ray, sc, qu = linear_out
+        fused = bev_sampling_fused(value, hw, query_ray.contiguous(), off, ray, sc, qu, time_diff, self.num_frames,
+                                   self.num_heads, self.num_points, self.depth_num, self.pc_range, d_region)
+        return self.attention.output_proj(fused) + query_feat
 
     def forward(self, query_ray, query_feat, bev_feats, img_metas, d_region=0.1):
         value, hw = self.prepare_value(bev_feats)
@@ -481,6 +506,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         self.reg_branch = nn.Sequential(*reg_branch)
         self.d_region_list = d_region_list
         self.num_ray = num_ray
+        self.fused = True  # False: the reference's op decomposition (torch keypoints + msmv / MSDA operators)
 
     @torch.no_grad()
     def init_weights(self):
@@ -498,11 +524,24 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         theta = bbox_proposal[..., 0:1] + (torch.sigmoid(bbox_delta[..., 0:1]) * 2 - 1) / self.num_ray
         return torch.cat([theta, dz_new, bbox_delta[..., 3:]], dim=-1)
 
+    def _wide_linears(self):
+        """The eleven Linear(256 -> .) layers that all read the post-norm1 query features, as one
+        [2189,256] GEMM operand (one rocBLAS call per layer instead of eleven)."""
+        mods = [self.sampling.sampling_offset, self.sampling.ray_points_offset, self.sampling.scale_weights]
+        for x in (self.sampling_radar_bev, self.sampling_lss_bev):
+            mods += [x.sampling_offset, x.ray_points_offset, x.scale_weights, x.attention.bev_queue_weight]
+        w = torch.cat([m.weight for m in mods], dim=0)
+        b = torch.cat([m.bias for m in mods], dim=0)
+        widths = [m.weight.shape[0] for m in mods]
+        return w, b, widths
+
     def prepare(self, lss_bev_feats, radar_bev_feats):
         """Layer-invariant tensors (computed once per forward)."""
         radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats)
         lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
-        return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw)
+        w, b, widths = self._wide_linears()
+        return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
+                    wide_w=w, wide_b=b, wide_widths=widths)
 
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
                 layer=0, prepared=None, stages=None):
@@ -514,13 +553,22 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         query_feat = query_feat + query_pos
         sa = self.self_attn(query_bbox, query_feat, attn_mask)
         query_feat = self.norm1(sa)
-        radar_raw = self.sampling_radar_bev.attend_prepared(query_bbox, query_feat, prepared["radar_value"],
-                                                            prepared["radar_hw"], time_diff, d_region)
-        lss_raw = self.sampling_lss_bev.attend_prepared(query_bbox, query_feat, prepared["lss_value"],
-                                                        prepared["lss_hw"], time_diff, d_region)
+        if self.fused:
+            lin = F.linear(query_feat, prepared["wide_w"], prepared["wide_b"]).split(prepared["wide_widths"], dim=-1)
+            radar_raw = self.sampling_radar_bev.attend_prepared(query_bbox, query_feat, prepared["radar_value"],
+                                                                prepared["radar_hw"], time_diff, d_region, lin[3:7])
+            lss_raw = self.sampling_lss_bev.attend_prepared(query_bbox, query_feat, prepared["lss_value"],
+                                                            prepared["lss_hw"], time_diff, d_region, lin[7:11])
+            sampled_feat = self.sampling(query_bbox, query_feat, mlvl_feats, img_metas, d_region=d_region,
+                                         linear_out=lin[0:3])
+        else:
+            radar_raw = self.sampling_radar_bev.attend_prepared_unfused(
+                query_bbox, query_feat, prepared["radar_value"], prepared["radar_hw"], time_diff, d_region)
+            lss_raw = self.sampling_lss_bev.attend_prepared_unfused(
+                query_bbox, query_feat, prepared["lss_value"], prepared["lss_hw"], time_diff, d_region)
+            sampled_feat = self.sampling.forward_unfused(query_bbox, query_feat, mlvl_feats, img_metas, d_region=d_region)
         query_radar_feat = self.norm_radar_bev(radar_raw)
         query_lss_feat = self.norm_lss_bev(lss_raw)
-        sampled_feat = self.sampling(query_bbox, query_feat, mlvl_feats, img_metas, d_region=d_region)
         mixed = self.mixing(sampled_feat, query_feat)
         query_feat = self.norm2(mixed)
         query_feat = self.norm_fusion(self.fusion(torch.cat((query_feat, query_radar_feat, query_lss_feat), dim=-1)))

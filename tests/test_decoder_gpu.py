@@ -16,8 +16,9 @@ DEV = "cuda:0"
 STAGES = ("position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_bev", "sampling", "mixing", "ffn")
 
 
-def run_gpu(cfg, seed, wseed, stages=None):
+def run_gpu(cfg, seed, wseed, stages=None, fused=True):
     tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+    tr.decoder.decoder_layer.fused = fused
     syn.fill_params(tr, wseed)
     tr = tr.to(DEV)
     qb, qf = syn.make_queries(cfg, seed)
@@ -29,24 +30,26 @@ def run_gpu(cfg, seed, wseed, stages=None):
     return cls.cpu(), box.cpu()
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name,cfg", [("decoder_small.npz", syn.SMALL), ("decoder_small6.npz", syn.SMALL6)])
-def test_decoder_small_vs_reference_golden(golden_dir, name, cfg):
+def test_decoder_small_vs_reference_golden(golden_dir, name, cfg, fused):
     g = np.load(os.path.join(golden_dir, name))
     stages = []
-    cls, box = run_gpu(cfg, int(g["seed"]), int(g["weight_seed"]), stages)
+    cls, box = run_gpu(cfg, int(g["seed"]), int(g["weight_seed"]), stages, fused)
     for s in STAGES:
         err = (stages[0][s].cpu() - torch.from_numpy(g[f"{s}_L0"])).abs().max().item()
         assert err < 1e-4, (s, err)
     decoder_parity(cls, box, g["cls"], g["box"], what=name)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name,cfg", [("decoder_f8.npz", syn.F8), ("decoder_f8_3cam.npz", syn.F8_3CAM)])
-def test_decoder_f8_vs_reference_golden(golden_dir, name, cfg):
+def test_decoder_f8_vs_reference_golden(golden_dir, name, cfg, fused):
     """BASELINE configs 3/5 shapes in fp32: box regressions within 1e-3, class argmax exact
     (criterion and its outlier allowance: tests/parity.py)."""
     g = np.load(os.path.join(golden_dir, name))
     stages = []
-    cls, box = run_gpu(cfg, int(g["seed"]), int(g["weight_seed"]), stages)
+    cls, box = run_gpu(cfg, int(g["seed"]), int(g["weight_seed"]), stages, fused)
     for s in STAGES:
         got = stages[0][s][:, :16].cpu()
         err = (got - torch.from_numpy(g[f"{s}_L0_head"])).abs().max().item()

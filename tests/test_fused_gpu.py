@@ -1,0 +1,77 @@
+"""Fused per-layer kernels (rac_sampling4d_fwd, rac_bev_sampling_fwd) against the CPU oracle and
+against the op-decomposed GPU path, on identical inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restate as R
+from racformer_amd import synthetic as syn
+from racformer_amd.transformer import RaCFormerTransformer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(cfg, seed, wseed):
+    tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+    syn.fill_params(tr, wseed)
+    sd = R._sub({k: v.clone() for k, v in tr.state_dict().items()}, "decoder.decoder_layer.")
+    tr = tr.to(DEV)
+    qb, qf = syn.make_queries(cfg, seed)
+    qf = qf * 5.0            # post-LayerNorm-like magnitude so offsets / logits are not degenerate
+    metas = syn.make_img_metas(cfg)
+    tr.decoder.stage_metas(metas, cfg.batch, torch.device(DEV))
+    return tr, sd, qb, qf, metas
+
+
+@pytest.mark.parametrize("cfg", [syn.SMALL, syn.SMALL6, syn.F8, syn.F8_3CAM])
+def test_sampling4d_fused(cfg):
+    tr, sd, qb, qf, metas = _setup(cfg, 21, 22)
+    layer = tr.decoder.decoder_layer
+    feats_cpu = R.regroup_pyramid(syn.make_pyramid(cfg, 21), cfg.num_cams)
+    feats = [f.to(DEV) for f in feats_cpu]
+    d_region = cfg.d_region_list[2]
+    with torch.no_grad():
+        out, loc, w = layer.sampling(qb.to(DEV), qf.to(DEV), feats, metas, d_region=d_region, debug=True)
+        out_unf = layer.sampling.forward_unfused(qb.to(DEV), qf.to(DEV), feats, metas, d_region=d_region)
+        td = R.time_diff_from_metas(syn.make_img_metas(cfg), cfg.batch, cfg.num_cams)
+        l2i = torch.from_numpy(np.asarray([m["lidar2img"] for m in syn.make_img_metas(cfg)]).astype(np.float32))
+        pts, sw = R.image_keypoints(sd, qb, qf, td, d_region, cfg)
+        B, Q, T, G, P, _ = pts.shape
+        oloc, oview, _ = R.project_select(pts.reshape(B, Q, T, G * P, 3), l2i, cfg.image_hw[0], cfg.image_hw[1])
+        oloc = oloc.reshape(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * T * G, Q, P, 3)
+        ref = R.sampling_4d(pts, feats_cpu, sw, l2i, cfg.image_hw[0], cfg.image_hw[1])
+    torch.cuda.synchronize()
+    loc, w, out, out_unf = loc.cpu(), w.cpu(), out.cpu(), out_unf.cpu()
+    N = cfg.num_cams
+    same_view = torch.round(loc[..., 2] * (N - 1)) == torch.round(oloc[..., 2] * (N - 1))
+    assert same_view.float().mean().item() > 0.9995, same_view.float().mean().item()
+    near = same_view & (oloc[..., 0].abs() < 2) & (oloc[..., 1].abs() < 2)
+    assert (loc[..., :2] - oloc[..., :2])[near].abs().max().item() < 2e-5
+    ow = sw.reshape(B, Q, G, T, P, -1).permute(0, 2, 3, 1, 4, 5).reshape(B * G * T, Q, P, -1)
+    assert (w - ow).abs().max().item() < 1e-5
+    # outputs: every (b,q,g,t) row whose 12 points chose the same cameras must match the oracle
+    row_ok = same_view.reshape(B, T, G, Q, P).all(-1).permute(0, 3, 2, 1)            # [B,Q,G,T]
+    err = (out - ref).reshape(B, Q, G, T, P, -1).abs().amax((-1, -2))
+    assert err[row_ok].max().item() < 2e-4, err[row_ok].max().item()
+    err_u = (out - out_unf).reshape(B, Q, G, T, P, -1).abs().amax((-1, -2))
+    assert err_u.median().item() < 1e-5 and (err_u > 2e-4).float().mean().item() < 1e-3
+
+
+@pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])
+def test_bev_sampling_fused(cfg):
+    tr, sd, qb, qf, metas = _setup(cfg, 31, 32)
+    layer = tr.decoder.decoder_layer
+    d_region = cfg.d_region_list[1]
+    lss = syn.make_bev(cfg, 31, 0)
+    td = R.time_diff_from_metas(syn.make_img_metas(cfg), cfg.batch, cfg.num_cams)
+    for name, temp in (("sampling_lss_bev", False), ("sampling_radar_bev", True)):
+        mod = getattr(layer, name)
+        with torch.no_grad():
+            value, hw = mod.prepare_value(lss.to(DEV))
+            got = mod.attend_prepared(qb.to(DEV), qf.to(DEV), value, hw, metas[0]["time_diff"], d_region)
+            unf = mod.attend_prepared_unfused(qb.to(DEV), qf.to(DEV), value, hw, metas[0]["time_diff"], d_region)
+            ref = R.bev_sampling(sd, name, qb, qf, lss, td, d_region, cfg, temp)
+        torch.cuda.synchronize()
+        assert (got.cpu() - ref).abs().max().item() < 2e-4, name
+        assert (got - unf).abs().max().item() < 1e-4, name

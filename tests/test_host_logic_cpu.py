@@ -43,6 +43,7 @@ def test_decoder_host_logic(golden_dir, host_ops, name, cfg):
     g = np.load(os.path.join(golden_dir, name))
     seed, wseed = int(g["seed"]), int(g["weight_seed"])
     tr = T.RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+    tr.decoder.decoder_layer.fused = False   # host logic of the op-decomposed plan
     syn.fill_params(tr, wseed)
     qb, qf = syn.make_queries(cfg, seed)
     stages = []

@@ -135,8 +135,8 @@ def main():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    msmv_ms = timer.mean_ms("msmv_fwd")
-    msda_ms = timer.mean_ms("msda_fwd")
+    msmv_ms = timer.mean_ms("sampling4d_fwd") or timer.mean_ms("msmv_fwd")
+    msda_ms = timer.mean_ms("bev_sampling_fwd") or timer.mean_ms("msda_fwd")
 
     # algorithmic bytes of the msmv launches of one forward (untimed, instrumented pass)
     cap = _lib.KernelTimer()
@@ -171,13 +171,13 @@ def main():
                                "layers + NMS-free decode, 1 sample/GPU/step",
                    "queries": cfg.num_query, "cams": cfg.num_cams, "frames": cfg.num_frames,
                    "levels": cfg.num_levels, "samples_per_gpu": 1, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "hbm", "kernel": "msmv_fwd_c64_kernel (rac_msmv_fwd)",
+        "roofline": {"bound": "hbm", "kernel": "sampling4d_c64_kernel (rac_sampling4d_fwd: keypoints + projection + view select + gather)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                      "avg_launch_ms": msmv_ms, "launches_per_step": len(cap.captured),
                      "algorithmic_bytes_per_launch": b_alg, "algorithmic_bytes_all_in_range": b_alg_closed,
                      "in_range_fraction_per_layer": in_frac,
-                     "msda_avg_launch_ms": msda_ms},
+                     "bev_sampling_avg_launch_ms": msda_ms},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

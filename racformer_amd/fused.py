@@ -45,6 +45,8 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
     p_sc, ld_sc = _rows(scale_logits, G * T * P * L, "sampling4d_fused(scale_logits)")
     out = torch.empty(B, Q, G, T * P, C, device=query_bbox.device, dtype=torch.float32)
     loc_out = w_out = None
+    capture = _lib.timer is not None and getattr(_lib.timer, "capture_inputs", False)
+    want_debug, debug = debug, debug or capture
     if debug:
         loc_out = torch.empty(S, Q, P, 3, device=out.device, dtype=torch.float32)
         w_out = torch.empty(S, Q, P, L, device=out.device, dtype=torch.float32)
@@ -62,7 +64,9 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
     if ev:
         ev[1].record()
     _lib.check(rc, "rac_sampling4d_fwd")
-    return (out, loc_out, w_out) if debug else out
+    if capture:  # bench.py: the locations this launch sampled at, for the algorithmic-byte count
+        _lib.timer.captured.append((loc_out, [tuple(f.shape) for f in feats]))
+    return (out, loc_out, w_out) if want_debug else out
 
 
 def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits, queue_logits, time_diff,

@@ -41,10 +41,27 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert lib.rac_abi_version() == 1
 
 
+def declared_params():
+    """name -> list of 'p' (pointer) / 'i' (int) / 'f' (float) per parameter, parsed from the header."""
+    out = {}
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for name, params in re.findall(r"\b(rac_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+            kinds = []
+            for prm in [x.strip() for x in params.split(",") if x.strip() and x.strip() != "void"]:
+                kinds.append("p" if "*" in prm else ("f" if prm.startswith("float") else "i"))
+            out[name] = kinds
+    return out
+
+
 def test_python_binding_covers_header(built_lib):
     from racformer_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     assert _lib.lib().rac_abi_version() == 1
+    kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f"}
+    for name, kinds in declared_params().items():
+        got = [kind[a] for a in _lib.SIGNATURES[name][1]]
+        assert got == kinds, f"{name}: ctypes argtypes {got} != header {kinds}"
 
 
 def test_argument_errors_need_no_gpu(built_lib):

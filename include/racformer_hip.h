@@ -20,6 +20,8 @@
  *                        models/racformer_transformer.py:112-124
  *   rac_sampling4d_fwd<- RaCFormerSampling.inner_forward + sampling_4d + msmv op, fused
  *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
+ *   rac_sasa_fwd      <- ScaleAdaptiveSelfAttention.inner_forward's mask + attention product
+ *                        models/racformer_transformer.py:296-335
  *   rac_bev_sampling_fwd <- BEVSampling keypoints + BEVSelfAttention's MSDA + frame fusion, fused
  *                        models/racformer_transformer.py:490-529, models/bev_self_attention.py:176-213
  */
@@ -112,6 +114,15 @@ int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float
                          int ld_scale, int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W,
                          int dim, const float *pc_range, const float *depth_base, float d_region, int dtype,
                          void *stream);
+
+/* Scale-adaptive self-attention core (QK^T + distance mask + softmax + AV), one kernel.
+ * Replaces calc_bbox_dists, the [B*heads,Q,Q] mask and nn.MultiheadAttention's attention product
+ * (models/racformer_transformer.py:296-335); in_proj / out_proj remain library GEMMs.
+ *   qkv : device f32, token row (b,q) at qkv + (b*Q+q)*ld_qkv holding q|k|v, each [heads, dim]
+ *   tau : device f32, rows of `heads` values, stride ld_tau (gen_tau Linear output)
+ *   out : device f32 [B,Q,heads*dim];  pc_range: HOST (6).  dim must be 32. */
+int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, float *out, int ld_qkv,
+                 int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,156 @@
+// sasa.hip -- scale-adaptive self-attention core as one kernel (gfx950).
+//
+// Replaces, per decoder layer, calc_bbox_dists (a [B,Q,Q] cdist), the [B*8,Q,Q] float mask, and
+// nn.MultiheadAttention's QK^T / softmax / AV (models/racformer_transformer.py:296-335 over mmcv's
+// MultiheadAttention wrapper): nothing of size Q x Q ever touches HBM.
+//   logits[b,h,i,j] = (q_i / sqrt(d)) . k_j  -  ||c_i - c_j||_2 * tau[b,i,h]
+//   out[b,i,h*d:(h+1)*d] = softmax_j(logits) @ v
+// with c = box centres in metres (decode_bbox(theta_d2xy(query_bbox))[:2], :301-302,:325).
+// in_proj / out_proj stay library GEMMs outside.
+//
+// Mapping: a workgroup = 16 query rows of one (batch, head); a 16-lane group owns a row, lane r of
+// the group walks keys j = r, r+16, ... with its own online-softmax state (running max, sum,
+// d-wide accumulator); the 16 partial states of a row are merged with a log-sum-exp butterfly over
+// the 16 lanes (wave64 DPP shuffles).  K/V rows (128 B each, head-contiguous) come straight from
+// L2 (the whole K|V of a head is 230 KB); centres of all keys are computed once per workgroup
+// into LDS.  fp32 throughout (exact-fp32 VALU; fp32 MFMA has the same rate on gfx950).
+#include "rac_common.h"
+
+#define SASA_D 32
+#define SASA_ROWS 16
+#define SASA_TWO_PI 6.283185307179586f
+
+struct SasaArgs {
+    const float *qkv;   // [B,Q,3,H,d]  (in_proj output)
+    const float *tau;   // [B,Q,H], row stride ld_tau
+    const float *qbox;  // [B,Q,10]
+    float *out;         // [B,Q,H*d]
+    float pc[6];
+    int B, Q, H, ld_tau, ld_qkv;
+    int row_blocks;
+};
+
+__global__ __launch_bounds__(256) void sasa_d32_kernel(const SasaArgs a)
+{
+    extern __shared__ float scen[];  // [Q][2] key centres (metres)
+    const int tid = threadIdx.x;
+    const int r = tid & 15, row = tid >> 4;
+    int bid = blockIdx.x;
+    const int rb = bid % a.row_blocks; bid /= a.row_blocks;
+    const int h = bid % a.H;
+    const int b = bid / a.H;
+    const int Q = a.Q, H = a.H;
+
+    for (int j = tid; j < Q; j += 256) {
+        const float *qb = a.qbox + ((size_t)b * Q + j) * 10;
+        const float ang = qb[0] * SASA_TWO_PI, rad = qb[1] * 65.0f;
+        const float xn = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f);
+        const float yn = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f);
+        scen[2 * j] = xn * (a.pc[3] - a.pc[0]) + a.pc[0];
+        scen[2 * j + 1] = yn * (a.pc[4] - a.pc[1]) + a.pc[1];
+    }
+    __syncthreads();
+
+    const int i = rb * SASA_ROWS + row;
+    const bool live = i < Q;
+    const int ii = live ? i : Q - 1;
+    const size_t tok = (size_t)b * Q;
+    const int ld = a.ld_qkv;  // floats per token row (>= 3*H*d: qkv may be a column slice of a wider GEMM output)
+    const float scale = 0.17677669529663687f;  // sqrt(1/32) as torch computes math.sqrt(1.0/d)
+    float q[SASA_D];
+    {
+        const rac_f4 *qp = reinterpret_cast<const rac_f4 *>(a.qkv + (tok + ii) * ld + h * SASA_D);
+#pragma unroll
+        for (int c = 0; c < SASA_D / 4; ++c) {
+            const rac_f4 t = qp[c];
+            q[4 * c] = t.x * scale; q[4 * c + 1] = t.y * scale; q[4 * c + 2] = t.z * scale; q[4 * c + 3] = t.w * scale;
+        }
+    }
+    const float tau = a.tau[(tok + ii) * a.ld_tau + h];
+    const float cix = scen[2 * ii], ciy = scen[2 * ii + 1];
+
+    float m = -INFINITY, l = 0.f;
+    float acc[SASA_D];
+#pragma unroll
+    for (int c = 0; c < SASA_D; ++c)
+        acc[c] = 0.f;
+
+    for (int j = r; j < Q; j += 16) {
+        const rac_f4 *kp = reinterpret_cast<const rac_f4 *>(a.qkv + (tok + j) * ld + (H + h) * SASA_D);
+        const rac_f4 *vp = reinterpret_cast<const rac_f4 *>(a.qkv + (tok + j) * ld + (2 * H + h) * SASA_D);
+        rac_f4 kk[SASA_D / 4], vv[SASA_D / 4];
+#pragma unroll
+        for (int c = 0; c < SASA_D / 4; ++c)
+            kk[c] = kp[c];
+#pragma unroll
+        for (int c = 0; c < SASA_D / 4; ++c)
+            vv[c] = vp[c];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < SASA_D / 4; ++c)
+            s += q[4 * c] * kk[c].x + q[4 * c + 1] * kk[c].y + q[4 * c + 2] * kk[c].z + q[4 * c + 3] * kk[c].w;
+        const float dx = cix - scen[2 * j], dy = ciy - scen[2 * j + 1];
+        s += -sqrtf(dx * dx + dy * dy) * tau;
+        const float mn = fmaxf(m, s);
+        const float corr = expf(m - mn);   // exp(-inf)=0 on the first key
+        const float p = expf(s - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int c = 0; c < SASA_D / 4; ++c) {
+            acc[4 * c] = acc[4 * c] * corr + p * vv[c].x;
+            acc[4 * c + 1] = acc[4 * c + 1] * corr + p * vv[c].y;
+            acc[4 * c + 2] = acc[4 * c + 2] * corr + p * vv[c].z;
+            acc[4 * c + 3] = acc[4 * c + 3] * corr + p * vv[c].w;
+        }
+        m = mn;
+    }
+    // merge the 16 lanes of the row: log-sum-exp butterfly
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        const float mo = __shfl_xor(m, off, 16);
+        const float lo = __shfl_xor(l, off, 16);
+        const float mn = fmaxf(m, mo);
+        const float ca = (m == -INFINITY) ? 0.f : expf(m - mn);
+        const float cb = (mo == -INFINITY) ? 0.f : expf(mo - mn);
+        l = l * ca + lo * cb;
+#pragma unroll
+        for (int c = 0; c < SASA_D; ++c) {
+            const float ao = __shfl_xor(acc[c], off, 16);
+            acc[c] = acc[c] * ca + ao * cb;
+        }
+        m = mn;
+    }
+    if (live) {
+        // lane r writes channels 2r, 2r+1 (all lanes hold the merged state)
+        const float inv = 1.f / l;
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < SASA_D / 2; ++c)
+            if (c == r) {
+                o0 = acc[2 * c];
+                o1 = acc[2 * c + 1];
+            }
+        float2 o = make_float2(o0 * inv, o1 * inv);
+        *reinterpret_cast<float2 *>(a.out + (tok + i) * (size_t)(H * SASA_D) + h * SASA_D + 2 * r) = o;
+    }
+}
+
+extern "C" int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, float *out, int ld_qkv,
+                            int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream)
+{
+    RAC_CHECK_ARG(dim == SASA_D, "rac_sasa_fwd: head dim %d (the kernel is built for %d)", dim, SASA_D);
+    RAC_CHECK_ARG(B >= 0 && Q >= 0 && heads >= 1 && ld_tau >= heads && ld_qkv >= 3 * heads * dim && ld_qkv % 4 == 0, "rac_sasa_fwd: bad sizes B=%d Q=%d heads=%d", B, Q, heads);
+    RAC_CHECK_ARG((size_t)Q * 2 * sizeof(float) <= 64 * 1024, "rac_sasa_fwd: Q=%d too large for the LDS centre table", Q);
+    if (B == 0 || Q == 0)
+        return 0;
+    RAC_CHECK_ARG(qkv && tau && query_bbox && out && pc_range, "rac_sasa_fwd: null pointer");
+    SasaArgs a;
+    a.qkv = qkv; a.tau = tau; a.qbox = query_bbox; a.out = out;
+    for (int i = 0; i < 6; ++i)
+        a.pc[i] = pc_range[i];
+    a.B = B; a.Q = Q; a.H = heads; a.ld_tau = ld_tau; a.ld_qkv = ld_qkv;
+    a.row_blocks = (Q + SASA_ROWS - 1) / SASA_ROWS;
+    const int nb = B * heads * a.row_blocks;
+    hipLaunchKernelGGL(sasa_d32_kernel, dim3(nb), dim3(256), (size_t)Q * 2 * sizeof(float), (hipStream_t)stream, a);
+    return rac_launch_status("rac_sasa_fwd");
+}

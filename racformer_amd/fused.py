@@ -97,3 +97,24 @@ def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits,
         ev[1].record()
     _lib.check(rc, "rac_bev_sampling_fwd")
     return (out, loc_out) if debug else out
+
+
+def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range):
+    """qkv [B,Q,3*E] (q|k|v, each [heads, E/heads]; may be a column slice), tau [B,Q,heads] ->
+    attention output [B,Q,E] before out_proj."""
+    _lib.require_gpu(query_bbox, what="sasa_fused")
+    B, Q, _ = query_bbox.shape
+    E = qkv.shape[-1] // 3
+    p_qkv, ld_qkv = _rows(qkv, 3 * E, "sasa_fused(qkv)")
+    p_tau, ld_tau = _rows(tau, num_heads, "sasa_fused(tau)")
+    out = torch.empty(B, Q, E, device=qkv.device, dtype=torch.float32)
+    pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    ev = _lib.timer.record("sasa_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_sasa_fwd(p_qkv, p_tau, _lib.ptr(query_bbox), _lib.ptr(out), ld_qkv, ld_tau, B, Q, num_heads,
+                                 E // num_heads, pc, _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_sasa_fwd")
+    return out

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import bev_sampling_fused, sampling4d_fused
+from .fused import bev_sampling_fused, sampling4d_fused, sasa_fused
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -98,6 +98,7 @@ class ScaleAdaptiveSelfAttention(nn.Module):
         self.num_heads = num_heads
         self.attention = _MHAHolder(embed_dims)
         self.gen_tau = nn.Linear(embed_dims, num_heads)
+        self.fused = True
 
     @torch.no_grad()
     def init_weights(self):
@@ -105,6 +106,18 @@ class ScaleAdaptiveSelfAttention(nn.Module):
         nn.init.uniform_(self.gen_tau.bias, 0.0, 2.0)
 
     def forward(self, query_bbox, query_feat, pre_attn_mask=None):
+        if self.fused and pre_attn_mask is None and self.embed_dims // self.num_heads == 32:
+            # one GEMM for in_proj + gen_tau, one HIP kernel for mask + QK^T + softmax + AV
+            p = self.attention.attn
+            w = torch.cat([p.in_proj_weight, self.gen_tau.weight], dim=0)
+            bias = torch.cat([p.in_proj_bias, self.gen_tau.bias], dim=0)
+            lin = F.linear(query_feat, w, bias)
+            E = self.embed_dims
+            o = sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], query_bbox.contiguous(), self.num_heads, self.pc_range)
+            return query_feat + p.out_proj(o)
+        return self.forward_unfused(query_bbox, query_feat, pre_attn_mask)
+
+    def forward_unfused(self, query_bbox, query_feat, pre_attn_mask=None):
         B, Q, E = query_feat.shape
         Hn, d = self.num_heads, E // self.num_heads
         centers = decode_bbox(theta_d2xy_coods(query_bbox), self.pc_range)[..., :2]
@@ -551,6 +564,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
         query_pos = self.position_encoder(query_bbox[..., :3])
         query_feat = query_feat + query_pos
+        self.self_attn.fused = self.fused
         sa = self.self_attn(query_bbox, query_feat, attn_mask)
         query_feat = self.norm1(sa)
         if self.fused:

@@ -75,3 +75,16 @@ def test_bev_sampling_fused(cfg):
         torch.cuda.synchronize()
         assert (got.cpu() - ref).abs().max().item() < 2e-4, name
         assert (got - unf).abs().max().item() < 1e-4, name
+
+
+@pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])
+def test_sasa_fused(cfg):
+    tr, sd, qb, qf, metas = _setup(cfg, 41, 42)
+    sa = tr.decoder.decoder_layer.self_attn
+    with torch.no_grad():
+        got = sa(qb.to(DEV), qf.to(DEV), None)
+        unf = sa.forward_unfused(qb.to(DEV), qf.to(DEV), None)
+        ref = R.sasa(sd, qb, qf, cfg.pc_range)
+    torch.cuda.synchronize()
+    assert (got.cpu() - ref).abs().max().item() < 2e-5
+    assert (got - unf).abs().max().item() < 2e-5

@@ -62,6 +62,22 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (separate FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads).  None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, "no profiles/*_pmc_traffic.json"
+    data = json.load(open(files[-1]))
+    for k, v in data.items():
+        if kernel_substr in k and v.get("read_bytes_corrected") is not None and v.get("write_bytes") is not None:
+            return v["read_bytes_corrected"] + v["write_bytes"], \
+                f"{os.path.basename(files[-1])}: 2*FETCH_SIZE + WRITE_SIZE, avg per launch (rocprofv3 --pmc, separate passes)"
+    return None, "kernel not in " + os.path.basename(files[-1])
+
+
 def msmv_algorithmic_bytes(loc, feat_shapes, elt_bytes, out_elems):
     """sum_l min(in-range points x 4 taps x C x s, level bytes) + loc + weights +
     output; `loc` is the [S,Q,P,3] tensor the kernel was launched with."""
@@ -157,6 +173,7 @@ def main():
     b_alg_closed = sum(min(n_pts * 4 * c * elt, s_ * n_ * h * w * c * elt) for (s_, n_, h, w, c) in full_shapes) \
         + n_pts * 3 * 4 + n_pts * cfg.num_levels * 4 + out_elems * 4
     achieved = b_alg / (msmv_ms * 1e-3) / 1e9 if msmv_ms else None
+    traffic, traffic_src = pmc_traffic("sampling4d_c64_kernel")
 
     result = {
         "metric": "samples/sec (6-cam 704x256, 900 queries, f8)" if args.config == "f8"
@@ -173,7 +190,8 @@ def main():
                    "levels": cfg.num_levels, "samples_per_gpu": 1, "parallelism": f"dp{world}"},
         "roofline": {"bound": "hbm", "kernel": "sampling4d_c64_kernel (rac_sampling4d_fwd: keypoints + projection + view select + gather)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "traffic_note": traffic_src,
                      "avg_launch_ms": msmv_ms, "launches_per_step": len(cap.captured),
                      "algorithmic_bytes_per_launch": b_alg, "algorithmic_bytes_all_in_range": b_alg_closed,
                      "in_range_fraction_per_layer": in_frac,

@@ -70,3 +70,14 @@ def test_no_cpu_fallback():
     with torch.no_grad(), pytest.raises(RuntimeError, match="CUDA tensor|not built"):
         tr(qb, qf, syn.make_pyramid(cfg, 1), syn.make_bev(cfg, 1, 0), syn.make_bev(cfg, 1, 1), None,
            syn.make_img_metas(cfg))
+
+
+def test_mixing_split_k_out_proj_is_equivalent():
+    """The split-K (batched) form of AdaptiveMixing.out_proj is the same linear map."""
+    torch.manual_seed(0)
+    mix = T.AdaptiveMixing(in_dim=256, in_points=12, n_groups=4, out_points=128).eval()
+    x, q = torch.randn(1, 5, 4, 12, 64), torch.randn(1, 5, 256)
+    with torch.no_grad():
+        a = mix(x, q)
+        b = mix(x, q, mix.split_out_proj())
+    assert (a - b).abs().max().item() < 1e-4

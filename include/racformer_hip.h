@@ -20,6 +20,8 @@
  *                        models/racformer_transformer.py:112-124
  *   rac_sampling4d_fwd<- RaCFormerSampling.inner_forward + sampling_4d + msmv op, fused
  *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
+ *   rac_mixing_fwd    <- AdaptiveMixing.inner_forward's matmul / layer_norm / relu chain
+ *                        models/racformer_transformer.py:589-603
  *   rac_sasa_fwd      <- ScaleAdaptiveSelfAttention.inner_forward's mask + attention product
  *                        models/racformer_transformer.py:296-335
  *   rac_bev_sampling_fwd <- BEVSampling keypoints + BEVSelfAttention's MSDA + frame fusion, fused
@@ -123,6 +125,16 @@ int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float
  *   out : device f32 [B,Q,heads*dim];  pc_range: HOST (6).  dim must be 32. */
 int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, float *out, int ld_qkv,
                  int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream);
+
+/* AdaptiveMixing core on the matrix cores (exact-fp32 MFMA): per (query, group) item
+ *   Y = relu(LN_{[P,64]}(x @ M)),  Z = relu(LN_{[128,64]}(S @ Y))
+ * Replaces the two batched matmuls, two layer norms and two ReLUs of AdaptiveMixing.inner_forward
+ * (models/racformer_transformer.py:589-603); parameter_generator / out_proj remain library GEMMs.
+ *   x      : device f32 [num_query, groups, in_points, 64]    (sampled features, B folded into num_query)
+ *   params : device f32, row q at params + q*ld_params, per group [64*64 (M, in x out) | 128*in_points (S)]
+ *   out    : device f32 [num_query, groups, 128, 64] */
+int rac_mixing_fwd(const float *x, const float *params, float *out, int ld_params, int num_query, int groups,
+                   int in_points, int channels, int out_points, float eps, void *stream);
 
 #ifdef __cplusplus
 }

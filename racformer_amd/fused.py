@@ -118,3 +118,24 @@ def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range):
         ev[1].record()
     _lib.check(rc, "rac_sasa_fwd")
     return out
+
+
+def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5):
+    """x [B,Q,G,P,64] (contiguous), params [B,Q,G*(64*64+128*P)] (unit inner stride) ->
+    relu(LN(S @ relu(LN(x @ M)))) as [B,Q,G*128*64], ready for out_proj."""
+    _lib.require_gpu(x, what="mixing_fused")
+    B, Q, G, P, C = x.shape
+    if G != n_groups or P != in_points or x.dtype != torch.float32:
+        raise RuntimeError("mixing_fused: x must be float32 [B,Q,G,P,64]")
+    width = G * (C * C + out_points * P)
+    p_par, ld_par = _rows(params, width, "mixing_fused(params)")
+    out = torch.empty(B, Q, G * out_points * C, device=x.device, dtype=torch.float32)
+    ev = _lib.timer.record("mixing_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_mixing_fwd(_lib.ptr(x), p_par, _lib.ptr(out), ld_par, B * Q, G, P, C, out_points, float(eps),
+                                   _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_mixing_fwd")
+    return out

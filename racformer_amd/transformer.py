@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import bev_sampling_fused, sampling4d_fused, sasa_fused
+from .fused import bev_sampling_fused, mixing_fused, sampling4d_fused, sasa_fused
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -474,7 +474,16 @@ class AdaptiveMixing(nn.Module):
     def forward(self, x, query, out_proj_split=None):
         B, Q, G, P, C = x.shape
         assert G == self.n_groups and P == self.in_points and C == self.eff_in_dim
-        params = self.parameter_generator(query).reshape(B * Q, G, -1)
+        params = self.parameter_generator(query)
+        if out_proj_split is not None and x.is_cuda and C == 64 and self.eff_out_dim == 64 and \
+                self.out_points == 128 and P <= 96:
+            # fused plan: one MFMA kernel for both mixings + norms + ReLUs, split-K out_proj
+            out = mixing_fused(x.contiguous(), params, P, G, self.out_points)
+            S_, N, k = out_proj_split.shape
+            a3 = out.view(B * Q, S_, k).transpose(0, 1)
+            proj = torch.bmm(a3, out_proj_split.transpose(1, 2)).sum(0) + self.out_proj.bias
+            return query + proj.view(B, Q, N)
+        params = params.reshape(B * Q, G, -1)
         M, S = params.split([self.m_parameters, self.s_parameters], 2)
         M = M.reshape(B * Q, G, self.eff_in_dim, self.eff_out_dim)
         S = S.reshape(B * Q, G, self.out_points, self.in_points)

@@ -88,3 +88,24 @@ def test_sasa_fused(cfg):
     torch.cuda.synchronize()
     assert (got.cpu() - ref).abs().max().item() < 2e-5
     assert (got - unf).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("P", [96, 36, 24, 7])
+def test_mixing_fused(P):
+    """rac_mixing_fwd (exact-fp32 MFMA) vs the torch formulation and the CPU oracle; P=96 is f8,
+    36/24 the reduced configs (padded tiles), 7 an odd size (unaligned S rows)."""
+    from racformer_amd.transformer import AdaptiveMixing
+    torch.manual_seed(P)
+    mix = AdaptiveMixing(in_dim=256, in_points=P, n_groups=4, out_points=128).eval()
+    Q = 37
+    x = torch.randn(1, Q, 4, P, 64)
+    q = torch.randn(1, Q, 256)
+    sd = {"mixing." + k: v.detach().clone() for k, v in mix.state_dict().items()}
+    with torch.no_grad():
+        ref = R.adaptive_mixing(sd, x, q)
+        mg = mix.to(DEV)
+        got = mg(x.to(DEV), q.to(DEV), mg.split_out_proj())
+        unf = mg(x.to(DEV), q.to(DEV))
+    torch.cuda.synchronize()
+    assert (got - unf).abs().max().item() < 2e-4
+    assert (got.cpu() - ref).abs().max().item() < 2e-4

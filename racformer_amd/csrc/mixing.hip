@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
     const int li = lane & 15, lk = lane >> 4;
     const int P = a.P;
     const int MT = (P + 15) >> 4;   // 16-row tiles of x / Y
-    const int PP = MT * 16;         // padded point count (K of the second product)
+    const int PP = MIX_PMAX;        // rows / K are always padded to 96 with zeros: branch-free MFMA loops
+    (void)MT;
     const int item = blockIdx.x;
     const int q = item / a.G, g = item % a.G;
     const float *gx = a.x + ((size_t)q * a.G + g) * P * MIX_C;
@@ -76,26 +77,19 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
     const float *gS = gM + MIX_C * MIX_C;
 
     // ---- stage x (zero rows up to PP), M and S half 0 -------------------------------------------
-    for (int i = tid; i < PP * 16; i += 256) {
-        const int r = i >> 4, c4 = i & 15;
+    // All global loads of the prologue are issued back to back into registers (16 x 16 B per thread)
+    // and only then written to LDS: one memory round trip per workgroup instead of one per loop trip.
+    const int ncol4 = PP >> 2;                 // float4 columns of a staged S row
+    const bool s_vec = (P & 3) == 0;           // S rows are 16-byte aligned
+    auto load_S = [&](int half, int k) -> rac_f4 {
+        // element k of this thread's share of S rows 64*half .. +63 (columns zero-padded to PP)
+        const int i = tid + 256 * k;
         rac_f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < P)
-            v = rac_ld4(gx + r * MIX_C + c4 * 4);
-        *reinterpret_cast<rac_f4 *>(sX + r * MIX_XS + c4 * 4) = v;
-    }
-    for (int i = tid; i < MIX_C * 16; i += 256) {
-        const int r = i >> 4, c4 = i & 15;
-        *reinterpret_cast<rac_f4 *>(sM + r * MIX_MS + c4 * 4) = rac_ld4(gM + r * MIX_C + c4 * 4);
-    }
-    auto stage_S = [&](int half) {
-        // rows 64*half .. +63 of S [128][P], columns zero-padded to PP
-        const int ncol4 = PP >> 2;
-        for (int i = tid; i < 64 * ncol4; i += 256) {
+        if (i < 64 * ncol4) {
             const int r = i / ncol4, c4 = i - r * ncol4;
             const float *src = gS + (size_t)(64 * half + r) * P + c4 * 4;
-            rac_f4 v = {0.f, 0.f, 0.f, 0.f};
             if (c4 * 4 + 3 < P) {
-                if ((P & 3) == 0) {
+                if (s_vec) {
                     v = rac_ld4(src);
                 } else {
                     v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
@@ -105,10 +99,47 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
                 if (c4 * 4 + 1 < P) v.y = src[1];
                 if (c4 * 4 + 2 < P) v.z = src[2];
             }
+        }
+        return v;
+    };
+    auto store_S = [&](int k, rac_f4 v) {
+        const int i = tid + 256 * k;
+        if (i < 64 * ncol4) {
+            const int r = i / ncol4, c4 = i - r * ncol4;
             *reinterpret_cast<rac_f4 *>(sS + r * MIX_SS + c4 * 4) = v;
         }
     };
-    stage_S(0);
+    {
+        rac_f4 vx[6], vm[4], vs[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {          // x: up to 96 rows x 16 float4
+            const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
+            vx[k] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+            if (r < P)
+                vx[k] = rac_ld4(gx + r * MIX_C + c4 * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {          // M: 64 rows x 16 float4
+            const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
+            vm[k] = rac_ld4(gM + r * MIX_C + c4 * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            vs[k] = load_S(0, k);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
+            *reinterpret_cast<rac_f4 *>(sX + r * MIX_XS + c4 * 4) = vx[k];   // rows >= P are zeros
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
+            *reinterpret_cast<rac_f4 *>(sM + r * MIX_MS + c4 * 4) = vm[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            store_S(k, vs[k]);
+    }
     __syncthreads();
 
     // ---- step 1: Y = x @ M, wave w -> columns 16w.. ---------------------------------------------
@@ -116,45 +147,44 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
 #pragma unroll
     for (int m = 0; m < 6; ++m)
         acc1[m] = (mix_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int s = 0; s < MIX_C / 4; ++s) {
         const float bv = sM[(4 * s + lk) * MIX_MS + 16 * wave + li];
+        float av[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m)
-            if (m < MT) {
-                const float av = sX[(16 * m + li) * MIX_XS + 4 * s + lk];
-                acc1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1[m], 0, 0, 0);
-            }
+            av[m] = sX[(16 * m + li) * MIX_XS + 4 * s + lk];
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+            acc1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc1[m], 0, 0, 0);
     }
     // LayerNorm over the P x 64 valid elements (rows >= P are padding: exact zeros, excluded)
     float part = 0.f;
 #pragma unroll
     for (int m = 0; m < 6; ++m)
-        if (m < MT)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                part += (16 * m + lk * 4 + r < P) ? acc1[m][r] : 0.f;
+        for (int r = 0; r < 4; ++r)
+            part += (16 * m + lk * 4 + r < P) ? acc1[m][r] : 0.f;
     const float n1 = (float)(P * MIX_C);
     const float mean1 = mix_block_sum(part, red, wave, lane) / n1;
     part = 0.f;
 #pragma unroll
     for (int m = 0; m < 6; ++m)
-        if (m < MT)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = acc1[m][r] - mean1;
-                part += (16 * m + lk * 4 + r < P) ? d * d : 0.f;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const float d = acc1[m][r] - mean1;
+            part += (16 * m + lk * 4 + r < P) ? d * d : 0.f;
+        }
     const float rstd1 = 1.f / sqrtf(mix_block_sum(part, red, wave, lane) / n1 + a.eps);
     // (the two block sums above end with barriers: every wave is past its last sX / sM read)
 #pragma unroll
     for (int m = 0; m < 6; ++m)
-        if (m < MT)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * m + lk * 4 + r;
-                const float y = fmaxf((acc1[m][r] - mean1) * rstd1, 0.f);
-                sY[row * MIX_MS + 16 * wave + li] = row < P ? y : 0.f;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * m + lk * 4 + r;
+            const float y = fmaxf((acc1[m][r] - mean1) * rstd1, 0.f);
+            sY[row * MIX_MS + 16 * wave + li] = row < P ? y : 0.f;
+        }
     __syncthreads();
 
     // ---- step 2: Z = S @ Y in two 64-row halves --------------------------------------------------
@@ -162,20 +192,29 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
 #pragma unroll
     for (int m = 0; m < 8; ++m)
         acc2[m] = (mix_f4){0.f, 0.f, 0.f, 0.f};
+    rac_f4 vs1[6];  // S half 1, fetched while half 0 is being multiplied
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        vs1[k] = load_S(1, k);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half == 1) {
             __syncthreads();  // all waves done reading S half 0
-            stage_S(1);
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                store_S(k, vs1[k]);
             __syncthreads();
         }
-        for (int s = 0; s < (PP >> 2); ++s) {
+#pragma unroll 4
+        for (int s = 0; s < MIX_PMAX / 4; ++s) {
             const float bv = sY[(4 * s + lk) * MIX_MS + 16 * wave + li];
+            float av[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float av = sS[(16 * m + li) * MIX_SS + 4 * s + lk];
-                acc2[4 * half + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc2[4 * half + m], 0, 0, 0);
-            }
+            for (int m = 0; m < 4; ++m)
+                av[m] = sS[(16 * m + li) * MIX_SS + 4 * s + lk];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                acc2[4 * half + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc2[4 * half + m], 0, 0, 0);
         }
     }
     part = 0.f;

@@ -8,12 +8,13 @@
 // with c = box centres in metres (decode_bbox(theta_d2xy(query_bbox))[:2], :301-302,:325).
 // in_proj / out_proj stay library GEMMs outside.
 //
-// Mapping: a workgroup = 16 query rows of one (batch, head); a 16-lane group owns a row, lane r of
-// the group walks keys j = r, r+16, ... with its own online-softmax state (running max, sum,
-// d-wide accumulator); the 16 partial states of a row are merged with a log-sum-exp butterfly over
-// the 16 lanes (wave64 DPP shuffles).  K/V rows (128 B each, head-contiguous) come straight from
-// L2 (the whole K|V of a head is 230 KB); centres of all keys are computed once per workgroup
-// into LDS.  fp32 throughout (exact-fp32 VALU; fp32 MFMA has the same rate on gfx950).
+// Mapping: a workgroup = 16 query rows of one (batch, head); a 16-lane group owns a row.  K/V are
+// streamed through LDS in 64-key tiles (next tile prefetched into registers while the current one
+// is consumed; row stride 36 floats = conflict-free ds_read_b128); lane r of a row scores keys
+// r, r+16, r+32, r+48 of the tile and folds them into its own online-softmax state (running max,
+// sum, d-wide accumulator) with one rescale per 4 keys; the 16 partial states of a row are merged
+// with a log-sum-exp butterfly over the 16 lanes.  Centres of all keys are computed once per
+// workgroup into LDS.  fp32 throughout (exact-fp32 VALU; fp32 MFMA has the same rate on gfx950).
 #include "rac_common.h"
 
 #define SASA_D 32
@@ -30,9 +31,15 @@ struct SasaArgs {
     int row_blocks;
 };
 
+#define SASA_TILE 64   /* keys per LDS tile */
+#define SASA_KS 36     /* LDS row stride (floats): 16-byte aligned and conflict-free for ds_read_b128 */
+
 __global__ __launch_bounds__(256) void sasa_d32_kernel(const SasaArgs a)
 {
-    extern __shared__ float scen[];  // [Q][2] key centres (metres)
+    extern __shared__ float smem[];
+    float *scen = smem;                       // [Q][2] key centres (metres)
+    float *sK = smem + 2 * ((a.Q + 1) & ~1);  // [64][36]
+    float *sV = sK + SASA_TILE * SASA_KS;     // [64][36]
     const int tid = threadIdx.x;
     const int r = tid & 15, row = tid >> 4;
     int bid = blockIdx.x;
@@ -40,6 +47,21 @@ __global__ __launch_bounds__(256) void sasa_d32_kernel(const SasaArgs a)
     const int h = bid % a.H;
     const int b = bid / a.H;
     const int Q = a.Q, H = a.H;
+    const size_t tok = (size_t)b * Q;
+    const int ld = a.ld_qkv;  // floats per token row (>= 3*H*d: qkv may be a column slice of a wider GEMM output)
+
+    // K/V tile staging: thread -> (key = tid/4 (0..63), 2 float4 of K and 2 of V at columns (tid%4)*2..)
+    const int sk = tid >> 2, sc = (tid & 3) * 2;
+    rac_f4 pk[2], pv[2];
+    auto prefetch = [&](int tile) {
+        const int j = tile * SASA_TILE + sk;
+        const int jj = j < Q ? j : Q - 1;
+        const rac_f4 *kp = reinterpret_cast<const rac_f4 *>(a.qkv + (tok + jj) * ld + (H + h) * SASA_D);
+        const rac_f4 *vp = reinterpret_cast<const rac_f4 *>(a.qkv + (tok + jj) * ld + (2 * H + h) * SASA_D);
+        pk[0] = kp[sc]; pk[1] = kp[sc + 1];
+        pv[0] = vp[sc]; pv[1] = vp[sc + 1];
+    };
+    prefetch(0);
 
     for (int j = tid; j < Q; j += 256) {
         const float *qb = a.qbox + ((size_t)b * Q + j) * 10;
@@ -49,13 +71,10 @@ __global__ __launch_bounds__(256) void sasa_d32_kernel(const SasaArgs a)
         scen[2 * j] = xn * (a.pc[3] - a.pc[0]) + a.pc[0];
         scen[2 * j + 1] = yn * (a.pc[4] - a.pc[1]) + a.pc[1];
     }
-    __syncthreads();
 
     const int i = rb * SASA_ROWS + row;
     const bool live = i < Q;
     const int ii = live ? i : Q - 1;
-    const size_t tok = (size_t)b * Q;
-    const int ld = a.ld_qkv;  // floats per token row (>= 3*H*d: qkv may be a column slice of a wider GEMM output)
     const float scale = 0.17677669529663687f;  // sqrt(1/32) as torch computes math.sqrt(1.0/d)
     float q[SASA_D];
     {
@@ -67,6 +86,7 @@ __global__ __launch_bounds__(256) void sasa_d32_kernel(const SasaArgs a)
         }
     }
     const float tau = a.tau[(tok + ii) * a.ld_tau + h];
+    __syncthreads();  // centres visible
     const float cix = scen[2 * ii], ciy = scen[2 * ii + 1];
 
     float m = -INFINITY, l = 0.f;
@@ -75,34 +95,54 @@ __global__ __launch_bounds__(256) void sasa_d32_kernel(const SasaArgs a)
     for (int c = 0; c < SASA_D; ++c)
         acc[c] = 0.f;
 
-    for (int j = r; j < Q; j += 16) {
-        const rac_f4 *kp = reinterpret_cast<const rac_f4 *>(a.qkv + (tok + j) * ld + (H + h) * SASA_D);
-        const rac_f4 *vp = reinterpret_cast<const rac_f4 *>(a.qkv + (tok + j) * ld + (2 * H + h) * SASA_D);
-        rac_f4 kk[SASA_D / 4], vv[SASA_D / 4];
+    const int ntiles = (Q + SASA_TILE - 1) / SASA_TILE;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        // publish the prefetched tile, start fetching the next one
+        *reinterpret_cast<rac_f4 *>(sK + sk * SASA_KS + sc * 4) = pk[0];
+        *reinterpret_cast<rac_f4 *>(sK + sk * SASA_KS + sc * 4 + 4) = pk[1];
+        *reinterpret_cast<rac_f4 *>(sV + sk * SASA_KS + sc * 4) = pv[0];
+        *reinterpret_cast<rac_f4 *>(sV + sk * SASA_KS + sc * 4 + 4) = pv[1];
+        __syncthreads();
+        if (tile + 1 < ntiles)
+            prefetch(tile + 1);
+        // lane r scores keys r, r+16, r+32, r+48 of the tile
+        float sc4[4];
 #pragma unroll
-        for (int c = 0; c < SASA_D / 4; ++c)
-            kk[c] = kp[c];
+        for (int u = 0; u < 4; ++u) {
+            const int kl = r + 16 * u, j = tile * SASA_TILE + kl;
+            const rac_f4 *kp = reinterpret_cast<const rac_f4 *>(sK + kl * SASA_KS);
+            float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < SASA_D / 4; ++c)
-            vv[c] = vp[c];
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < SASA_D / 4; ++c)
-            s += q[4 * c] * kk[c].x + q[4 * c + 1] * kk[c].y + q[4 * c + 2] * kk[c].z + q[4 * c + 3] * kk[c].w;
-        const float dx = cix - scen[2 * j], dy = ciy - scen[2 * j + 1];
-        s += -sqrtf(dx * dx + dy * dy) * tau;
-        const float mn = fmaxf(m, s);
-        const float corr = expf(m - mn);   // exp(-inf)=0 on the first key
-        const float p = expf(s - mn);
-        l = l * corr + p;
-#pragma unroll
-        for (int c = 0; c < SASA_D / 4; ++c) {
-            acc[4 * c] = acc[4 * c] * corr + p * vv[c].x;
-            acc[4 * c + 1] = acc[4 * c + 1] * corr + p * vv[c].y;
-            acc[4 * c + 2] = acc[4 * c + 2] * corr + p * vv[c].z;
-            acc[4 * c + 3] = acc[4 * c + 3] * corr + p * vv[c].w;
+            for (int c = 0; c < SASA_D / 4; ++c) {
+                const rac_f4 kk = kp[c];
+                s += q[4 * c] * kk.x + q[4 * c + 1] * kk.y + q[4 * c + 2] * kk.z + q[4 * c + 3] * kk.w;
+            }
+            const int jc = j < Q ? j : Q - 1;
+            const float dx = cix - scen[2 * jc], dy = ciy - scen[2 * jc + 1];
+            s += -sqrtf(dx * dx + dy * dy) * tau;
+            sc4[u] = j < Q ? s : -INFINITY;
         }
-        m = mn;
+        const float mn = fmaxf(fmaxf(m, fmaxf(sc4[0], sc4[1])), fmaxf(sc4[2], sc4[3]));
+        if (mn > -INFINITY) {
+            const float corr = (m == -INFINITY) ? 0.f : expf(m - mn);
+            l *= corr;
+#pragma unroll
+            for (int c = 0; c < SASA_D; ++c)
+                acc[c] *= corr;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float p = (sc4[u] == -INFINITY) ? 0.f : expf(sc4[u] - mn);
+                l += p;
+                const rac_f4 *vp = reinterpret_cast<const rac_f4 *>(sV + (r + 16 * u) * SASA_KS);
+#pragma unroll
+                for (int c = 0; c < SASA_D / 4; ++c) {
+                    const rac_f4 vv = vp[c];
+                    acc[4 * c] += p * vv.x; acc[4 * c + 1] += p * vv.y; acc[4 * c + 2] += p * vv.z; acc[4 * c + 3] += p * vv.w;
+                }
+            }
+            m = mn;
+        }
+        __syncthreads();  // everyone done with this tile before it is overwritten
     }
     // merge the 16 lanes of the row: log-sum-exp butterfly
 #pragma unroll
@@ -151,6 +191,7 @@ extern "C" int rac_sasa_fwd(const float *qkv, const float *tau, const float *que
     a.B = B; a.Q = Q; a.H = heads; a.ld_tau = ld_tau; a.ld_qkv = ld_qkv;
     a.row_blocks = (Q + SASA_ROWS - 1) / SASA_ROWS;
     const int nb = B * heads * a.row_blocks;
-    hipLaunchKernelGGL(sasa_d32_kernel, dim3(nb), dim3(256), (size_t)Q * 2 * sizeof(float), (hipStream_t)stream, a);
+    const size_t lds = ((size_t)2 * ((Q + 1) & ~1) + 2 * SASA_TILE * SASA_KS) * sizeof(float);
+    hipLaunchKernelGGL(sasa_d32_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_sasa_fwd");
 }

@@ -105,13 +105,19 @@ class ScaleAdaptiveSelfAttention(nn.Module):
         nn.init.zeros_(self.gen_tau.weight)
         nn.init.uniform_(self.gen_tau.bias, 0.0, 2.0)
 
-    def forward(self, query_bbox, query_feat, pre_attn_mask=None):
+    def wide_in_proj(self):
+        """in_proj and gen_tau as one [776,256] GEMM operand (built once per forward)."""
+        p = self.attention.attn
+        return (torch.cat([p.in_proj_weight, self.gen_tau.weight], dim=0),
+                torch.cat([p.in_proj_bias, self.gen_tau.bias], dim=0))
+
+    def forward(self, query_bbox, query_feat, pre_attn_mask=None, prepared_w=None):
         if self.fused and pre_attn_mask is None and self.embed_dims // self.num_heads == 32:
             # one GEMM for in_proj + gen_tau, one HIP kernel for mask + QK^T + softmax + AV
             p = self.attention.attn
-            w = torch.cat([p.in_proj_weight, self.gen_tau.weight], dim=0)
-            bias = torch.cat([p.in_proj_bias, self.gen_tau.bias], dim=0)
-            lin = F.linear(query_feat, w, bias)
+            if prepared_w is None:
+                prepared_w = self.wide_in_proj()
+            lin = F.linear(query_feat, prepared_w[0], prepared_w[1])
             E = self.embed_dims
             o = sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], query_bbox.contiguous(), self.num_heads, self.pc_range)
             return query_feat + p.out_proj(o)
@@ -329,12 +335,21 @@ class BEVSelfAttention(nn.Module):
             nn.init.xavier_uniform_(m.weight)
             nn.init.constant_(m.bias, 0.0)
 
-    def project_value(self, value_maps):
-        """value_maps [B,T,C,H,W] -> [B*T, H*W, heads, C/heads] (bev_self_attention.py:162-174).
-        Query-independent: the decoder calls this once per forward, not once per layer."""
+    def project_value(self, value_maps, pos=None):
+        """value_maps [B,T,C,H,W] (+ optional positional map [C,H,W] added to every frame) ->
+        [B*T, H*W, heads, C/heads] (bev_self_attention.py:162-174).  Query-independent: the decoder
+        calls this once per forward, not once per layer.  value_proj is linear, so
+        value_proj(bev + pos) = bev^T W^T + (pos^T W^T + b): the frame-independent term is projected
+        once ([HW,C] GEMM) and enters as the GEMM's additive operand, and the [C,HW] -> [HW,C]
+        transpose is the GEMM's own operand transposition -- no bev+pos tensor, no permute copy."""
         B, T, C, H, W = value_maps.shape
-        v = value_maps.reshape(B * T, C, H * W).permute(0, 2, 1)
-        return self.value_proj(v).reshape(B * T, H * W, self.num_heads, C // self.num_heads).contiguous()
+        wt = self.value_proj.weight.t()
+        if pos is None:
+            bias = self.value_proj.bias.view(1, 1, C).expand(B * T, H * W, C)
+        else:
+            bias = self.value_proj(pos.reshape(C, H * W).t()).unsqueeze(0).expand(B * T, H * W, C)
+        v = torch.baddbmm(bias, value_maps.reshape(B * T, C, H * W).transpose(1, 2), wt.unsqueeze(0).expand(B * T, C, C))
+        return v.view(B * T, H * W, self.num_heads, C // self.num_heads)
 
     def attend(self, query, value, sampling_locations, attention_weights, spatial_shapes, identity=None):
         """value: projected [B*T, HW, heads, D]; sampling_locations [B,Q,heads,T,P,2];
@@ -398,7 +413,7 @@ class BEVSampling(nn.Module):
             bev_feats = self.temporal_encoder(bev_feats)
         H, W = bev_feats.shape[-2:]
         pos = self.positional_encoding.grid(H, W).to(bev_feats.dtype)
-        return self.attention.project_value(bev_feats + pos[None, None]), (H, W)
+        return self.attention.project_value(bev_feats, pos), (H, W)
 
     def keypoints(self, query_ray, query_feat, time_diff, d_region):
         """-> loc [B,Q,heads,T,P,2] in [0,1], weights [B,Q,heads,T,1,P] (:490-529)."""
@@ -579,7 +594,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
         w, b, widths = self._wide_linears()
         return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
-                    wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=self.mixing.split_out_proj())
+                    wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=self.mixing.split_out_proj(),
+                    sasa_w=self.self_attn.wide_in_proj())
 
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
                 layer=0, prepared=None, stages=None):
@@ -590,7 +606,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         query_pos = self.position_encoder(query_bbox[..., :3])
         query_feat = query_feat + query_pos
         self.self_attn.fused = self.fused
-        sa = self.self_attn(query_bbox, query_feat, attn_mask)
+        sa = self.self_attn(query_bbox, query_feat, attn_mask, prepared.get("sasa_w") if self.fused else None)
         query_feat = self.norm1(sa)
         if self.fused:
             lin = F.linear(query_feat, prepared["wide_w"], prepared["wide_b"]).split(prepared["wide_widths"], dim=-1)

@@ -18,6 +18,7 @@
  *                        models/multi_scale_deformable_attn_function.py:118-124
  *   rac_regroup_fwd   <- the channel-last regroup in RaCFormerTransformerDecoder.forward,
  *                        models/racformer_transformer.py:112-124
+ *   rac_box_prep_fwd  <- decode_bbox(theta_d2xy_coods(.)) models/bbox/utils.py:66-90 (shared prologue)
  *   rac_sampling4d_fwd<- RaCFormerSampling.inner_forward + sampling_4d + msmv op, fused
  *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
  *   rac_mixing_fwd    <- AdaptiveMixing.inner_forward's matmul / layer_norm / relu chain
@@ -82,11 +83,17 @@ int rac_msda_fwd(const void *value, const int64_t *shapes, const int64_t *starts
 int rac_regroup_fwd(const float *in, void *out, int B, int T, int N, int G, int C, int H, int W,
                     int out_dtype, void *stream);
 
+/* Per-query box constants shared by the fused sampling kernels: table[b,q] = (cx, cy, cz, w, l, h,
+ * cos yaw, sin yaw) = decode_bbox(theta_d2xy_coods(query_bbox)) (models/bbox/utils.py:66-90), once per
+ * query and layer instead of once per keypoint.  query_bbox device f32 [n,10], table device f32 [n,8]. */
+int rac_box_prep_fwd(const float *query_bbox, float *table, int num_boxes, const float *pc_range, void *stream);
+
 /* Adaptive 4D sampling of one decoder layer, fully fused (keypoints -> projection -> first-valid-view
  * -> multi-scale gather).  Replaces RaCFormerSampling.inner_forward + sampling_4d + the msmv op
  * (models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134).
  *   feats[l]     : device [B*T*G, N, H_l, W_l, 64] (dtype), hw HOST L x (H,W)
  *   query_bbox   : device f32 [B,Q,10] polar boxes (theta, d, z, log w, log l, log h, sin, cos, vx, vy)
+ *   box_table    : device f32 [B,Q,8] written by rac_box_prep_fwd for the same boxes
  *   offsets      : device f32, row (b,q) at offsets + (b*Q+q)*ld_off, G*NP*D*3 values (sampling_offset Linear)
  *   ray_logits   : device f32, rows of D values, stride ld_ray          (ray_points_offset Linear)
  *   scale_logits : device f32, rows of G*T*NP*D*L values, stride ld_scale (scale_weights Linear, softmax over L here)
@@ -95,7 +102,7 @@ int rac_regroup_fwd(const float *in, void *out, int B, int T, int N, int G, int 
  *   loc_out,w_out: optional debug outputs [S,Q,P,3] (u,v,view/(N-1)) and [S,Q,P,L] (NULL,NULL to skip)
  *   pc_range (6), depth_base (D = torch.linspace(-d_region,d_region,D)): HOST pointers */
 int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox,
-                       const float *offsets, const float *ray_logits, const float *scale_logits,
+                       const float *box_table, const float *offsets, const float *ray_logits, const float *scale_logits,
                        const float *time_diff, const float *lidar2img, float *out, float *loc_out,
                        float *w_out, int ld_off, int ld_ray, int ld_scale, int B, int T, int N, int G, int Q,
                        int NP, int D, int C, const float *pc_range, const float *depth_base, float d_region,
@@ -110,7 +117,7 @@ int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const
  *   scale_logits : rows of heads*NP*D (ld_scale, softmax over the NP*D points of a head here);
  *   queue_logits : rows of T (ld_queue, softmax over frames here)
  *   out          : device f32 [B,Q,heads*64];  loc_out: optional [B,Q,heads,T,NP*D,2] or NULL */
-int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float *offsets,
+int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float *box_table, const float *offsets,
                          const float *ray_logits, const float *scale_logits, const float *queue_logits,
                          const float *time_diff, float *out, float *loc_out, int ld_off, int ld_ray,
                          int ld_scale, int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W,

@@ -22,10 +22,11 @@ SIGNATURES = {
     "rac_msmv_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rac_msda_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rac_regroup_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "rac_sampling4d_fwd": (_i, [_vp, _vp, _i] + [_vp] * 9 + [_i] * 3 + [_i] * 8 + [_vp, _vp] + [_f] * 4 + [_i, _vp]),
+    "rac_box_prep_fwd": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "rac_sampling4d_fwd": (_i, [_vp, _vp, _i] + [_vp] * 10 + [_i] * 3 + [_i] * 8 + [_vp, _vp] + [_f] * 4 + [_i, _vp]),
     "rac_mixing_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_f, _vp]),
     "rac_sasa_fwd": (_i, [_vp] * 4 + [_i] * 6 + [_vp, _vp]),
-    "rac_bev_sampling_fwd": (_i, [_vp] * 9 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
+    "rac_bev_sampling_fwd": (_i, [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
 }
 
 

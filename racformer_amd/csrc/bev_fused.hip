@@ -9,21 +9,23 @@
 // logits), the frame logits (bev_queue_weight), query boxes, time_diff and the hoisted value
 // stream [B*T, H*W, heads, 64]; output [B,Q,heads*64] (before output_proj).
 //
-// Workgroup = 16 items (b,q,head) = 4 queries x 4 heads; a 16-lane group owns an item (4 channels
-// per lane, 16-byte loads).  Phase 0: softmaxes (point weights per item, frame weights per query)
-// into LDS.  Phase 1: all threads compute the items' T*P keypoints into LDS.  Phase 2: per frame,
-// 20 points unrolled by 4 (16 taps in flight), accumulate, scale by the frame weight.
+// Workgroup = 4 items (b,q,head) (one query's 4 heads) x 4 frame subsets: a 16-lane group owns
+// (item, frames ts, ts+4, ...) with 4 channels per lane (16-byte loads).  Phase A: the T-invariant
+// pieces once per item -- base points from the box table (rac_box_prep_fwd), ray-depth offsets, the
+// two softmaxes -- into LDS.  Phase B: all threads warp the base points to every frame (T*P
+// keypoints per item).  Phase C: per frame 20 points unrolled by 4 (16 taps in flight), scaled by
+// the frame weight.  Phase D: fixed-order LDS sum of the four frame subsets (deterministic).
 // For B>1 the reference pairs value frame i=b*T+t with the locations of (t'=i/B, b'=i%B)
 // (bev_self_attention.py:185-188 vs :162,173, quirk Q2); reproduced as written.
 #include "rac_common.h"
 
-#define BEV_ITEMS 16
 #define BEV_MAX_DEPTH 16
 #define BEV_TWO_PI 6.283185307179586f
 
 struct BevArgs {
     const void *value;
     const float *qbox;       // [B,Q,10]
+    const float *box;        // [B,Q,8] from rac_box_prep_fwd
     const float *off;        // [B,Q,heads*P*2]
     const float *ray;        // [B,Q,D]
     const float *scale;      // [B,Q,heads*P] logits
@@ -77,30 +79,66 @@ __device__ __forceinline__ rac_f4 bev_tap(const FT *base, long pix, int stride, 
     return v;
 }
 
+#define BEV_GI 4   /* items (b,q,head) per workgroup */
+#define BEV_TS 4   /* frame subsets per item: 16-lane group (k, ts) handles frames ts, ts+4, ... */
+
+// per-(t,p) half of the keypoint chain for B==1: warp the T-invariant base point, polar jitter.
+__device__ __forceinline__ void bev_warp(const BevArgs &a, float px, float py, float vx, float vy, float td,
+                                         float doff, float *loc2)
+{
+    const float sx = a.pc[3] - a.pc[0], sy = a.pc[4] - a.pc[1];
+    px -= vx * td;
+    py -= vy * td;
+    const float nx = (px - a.pc[0]) / sx, ny = (py - a.pc[1]) / sy;
+    const float ex = nx * 102.4f - 51.2f, ey = ny * 102.4f - 51.2f;
+    const float dist = sqrtf(ex * ex + ey * ey) / 65.0f + doff;
+    const float th = fmodf(atan2f(ey, ex) + BEV_TWO_PI, BEV_TWO_PI) / BEV_TWO_PI;
+    const float ang = th * BEV_TWO_PI, rad = dist * 65.0f;
+    loc2[0] = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f);
+    loc2[1] = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f);
+}
+
 template <typename FT>
 __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x;
     const int c4 = tid & 15, grp = tid >> 4;
-    const int T = a.T, P = a.P, TP = a.T * a.P;
+    const int k = grp >> 2, ts = grp & 3;       // item within the workgroup, frame subset
+    const int T = a.T, P = a.P, TP = a.T * a.P, D = a.D;
 
     const int per_b = a.Q * a.heads;
     const int b = blockIdx.x / a.blocks_per_b;
-    const int i0 = (blockIdx.x % a.blocks_per_b) * BEV_ITEMS;
-    const int nitems = min(BEV_ITEMS, per_b - i0);
+    const int i0 = (blockIdx.x % a.blocks_per_b) * BEV_GI;
+    const int nitems = min(BEV_GI, per_b - i0);
 
-    float *sloc = smem;                         // [items][T][P][2]
-    float *sattn = sloc + BEV_ITEMS * TP * 2;   // [items][P]
-    float *sq = sattn + BEV_ITEMS * P;          // [items][T]
+    float *sloc = smem;                        // [GI][T][P][2]
+    float *sattn = sloc + BEV_GI * TP * 2;     // [GI][P]
+    float *sq = sattn + BEV_GI * P;            // [GI][T]
+    float *sbase = sq + BEV_GI * T;            // [GI][P][2]  T-invariant base points (B==1)
+    float *sdoff = sbase + BEV_GI * P * 2;     // [GI][D]
+    float *spart = sdoff + BEV_GI * BEV_MAX_DEPTH;  // [GI][TS][64] partial sums
 
-    // phase 0: softmaxes.  thread k<nitems: point weights of item k (from batch b' of frame 0 ...
-    // the weights are frame-independent in value but follow the same (t',b') pairing as loc; since
-    // they are expanded over T unchanged, only b' matters and b' depends on t for B>1.  Keep it
-    // simple and exact: store per (item, t) the source batch, recompute weights per source batch).
-    // For B==1 (the supported deployment, val.py:60) b' == b for every t.
-    if (tid < nitems) {
-        const int it = i0 + tid, q = it / a.heads, h = it % a.heads;
+    // phase A: T-invariant pieces.  threads [0, GI*P): base points; [128,128+GI*D): depth offsets;
+    // [192,192+GI): softmaxes of the point weights and of the frame weights.
+    if (tid < nitems * P && a.B == 1) {
+        const int kk = tid / P, p = tid - kk * P;
+        const int it = i0 + kk, q = it / a.heads, h = it % a.heads;
+        const float *bt = a.box + ((size_t)b * a.Q + q) * 8;
+        const float *o = a.off + ((size_t)b * a.Q + q) * a.ld_off + ((size_t)h * P + p) * 2;
+        const float dx = bt[3] * o[0], dy = bt[4] * o[1];
+        sbase[tid * 2] = bt[0] + (dx * bt[6] - dy * bt[7]);
+        sbase[tid * 2 + 1] = bt[1] + (dx * bt[7] + dy * bt[6]);
+    }
+    if (tid >= 128 && tid < 128 + nitems * D && a.B == 1) {
+        const int kk = (tid - 128) / D, dd = (tid - 128) - kk * D;
+        const int q = (i0 + kk) / a.heads;
+        const float sg = 1.f / (1.f + expf(-a.ray[((size_t)b * a.Q + q) * a.ld_ray + dd]));
+        sdoff[kk * BEV_MAX_DEPTH + dd] = a.depth_base[dd] + (sg * 2.f - 1.f) * a.d_region / (float)D / 2.f;
+    }
+    if (tid >= 192 && tid < 192 + nitems) {
+        const int kk = tid - 192;
+        const int it = i0 + kk, q = it / a.heads, h = it % a.heads;
         const float *qg = a.queue + ((size_t)b * a.Q + q) * a.ld_queue;
         float mx = qg[0];
         for (int t = 1; t < T; ++t)
@@ -108,11 +146,11 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
         float sum = 0.f;
         for (int t = 0; t < T; ++t) {
             const float e = expf(qg[t] - mx);
-            sq[tid * T + t] = e;
+            sq[kk * T + t] = e;
             sum += e;
         }
         for (int t = 0; t < T; ++t)
-            sq[tid * T + t] /= sum;
+            sq[kk * T + t] /= sum;
         if (a.B == 1) {
             const float *lg = a.scale + ((size_t)b * a.Q + q) * a.ld_scale + (size_t)h * P;
             float m2 = lg[0];
@@ -121,20 +159,27 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
             float s2 = 0.f;
             for (int p = 0; p < P; ++p) {
                 const float e = expf(lg[p] - m2);
-                sattn[tid * P + p] = e;
+                sattn[kk * P + p] = e;
                 s2 += e;
             }
             for (int p = 0; p < P; ++p)
-                sattn[tid * P + p] /= s2;
+                sattn[kk * P + p] /= s2;
         }
     }
-    // phase 1: keypoints
+    __syncthreads();
+    // phase B: per-frame keypoints
     for (int i = tid; i < nitems * TP; i += 256) {
-        const int k = i / TP, r = i - k * TP, t = r / P, p = r - t * P;
-        const int it = i0 + k, q = it / a.heads, h = it % a.heads;
-        const int fi = b * T + t;               // value frame index
-        const int bq = fi % a.B, tq = fi / a.B;  // whose locations it is paired with (quirk Q2)
-        bev_keypoint(a, bq, tq, q, h, p, sloc + i * 2);
+        const int kk = i / TP, r = i - kk * TP, t = r / P, p = r - t * P;
+        const int it = i0 + kk, q = it / a.heads, h = it % a.heads;
+        if (a.B == 1) {
+            const float *qb = a.qbox + ((size_t)b * a.Q + q) * 10;
+            bev_warp(a, sbase[(kk * P + p) * 2], sbase[(kk * P + p) * 2 + 1], qb[8], qb[9], a.time_diff[b * T + t],
+                     sdoff[kk * BEV_MAX_DEPTH + p % D], sloc + i * 2);
+        } else {
+            const int fi = b * T + t;                // value frame index
+            const int bq = fi % a.B, tq = fi / a.B;  // whose locations it is paired with (quirk Q2)
+            bev_keypoint(a, bq, tq, q, h, p, sloc + i * 2);
+        }
         if (a.loc_out) {
             float *lo = a.loc_out + (((((size_t)b * a.Q + q) * a.heads + h) * T + t) * P + p) * 2;
             lo[0] = sloc[i * 2];
@@ -142,77 +187,90 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
         }
     }
     __syncthreads();
-    if (grp >= nitems)
-        return;
-    const int it = i0 + grp, q = it / a.heads, h = it % a.heads;
-    const int H = a.H, W = a.W, stride = a.heads * 64;
-    const long keys = (long)H * W;
 
     rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < T; ++t) {
-        const int fi = b * T + t;
-        const FT *base = (const FT *)a.value + ((size_t)fi * keys * a.heads + h) * 64 + c4 * 4;
-        const float *lp = sloc + (grp * TP + t * P) * 2;
-        const float *ap = sattn + grp * P;
-        float wsum_inv = 1.f, wmax = 0.f;
-        const float *lg = nullptr;
-        if (a.B > 1) {  // recompute the point softmax from the paired batch b' (rare path)
-            const int bq = fi % a.B;
-            lg = a.scale + ((size_t)bq * a.Q + q) * a.ld_scale + (size_t)h * P;
-            wmax = lg[0];
-            for (int p = 1; p < P; ++p)
-                wmax = fmaxf(wmax, lg[p]);
-            float s2 = 0.f;
-            for (int p = 0; p < P; ++p)
-                s2 += expf(lg[p] - wmax);
-            wsum_inv = 1.f / s2;
-        }
-        rac_f4 at = {0.f, 0.f, 0.f, 0.f};
-        for (int p0 = 0; p0 < P; p0 += 4) {
-            rac_f4 v[4][4];
-            float tw[4][4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int p = p0 + k;
-                const bool act = p < P;
-                const int pp = act ? p : P - 1;
-                const float x = lp[pp * 2], y = lp[pp * 2 + 1];
-                float wgt = a.B > 1 ? expf(lg[pp] - wmax) * wsum_inv : ap[pp];
-                wgt = act ? wgt : 0.f;
-                const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
-                const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                const float hf = floorf(h_im), wf = floorf(w_im);
-                const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
-                const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-                v[k][0] = bev_tap(base, (long)h_low * W + w_low, stride, t_ok && l_ok);
-                v[k][1] = bev_tap(base, (long)h_low * W + w_high, stride, t_ok && r_ok);
-                v[k][2] = bev_tap(base, (long)h_high * W + w_low, stride, b_ok && l_ok);
-                v[k][3] = bev_tap(base, (long)h_high * W + w_high, stride, b_ok && r_ok);
-                tw[k][0] = hh * hw * wgt;
-                tw[k][1] = hh * lw * wgt;
-                tw[k][2] = lh * hw * wgt;
-                tw[k][3] = lh * lw * wgt;
+    const bool live = k < nitems;
+    const int it = i0 + (live ? k : 0), q = it / a.heads, h = it % a.heads;
+    const int H = a.H, W = a.W, stride = a.heads * 64;
+    const long keys = (long)H * W;
+    if (live) {
+        for (int t = ts; t < T; t += BEV_TS) {
+            const int fi = b * T + t;
+            const FT *base = (const FT *)a.value + ((size_t)fi * keys * a.heads + h) * 64 + c4 * 4;
+            const float *lp = sloc + (k * TP + t * P) * 2;
+            const float *ap = sattn + k * P;
+            float wsum_inv = 1.f, wmax = 0.f;
+            const float *lg = nullptr;
+            if (a.B > 1) {  // recompute the point softmax from the paired batch b' (rare path)
+                const int bq = fi % a.B;
+                lg = a.scale + ((size_t)bq * a.Q + q) * a.ld_scale + (size_t)h * P;
+                wmax = lg[0];
+                for (int p = 1; p < P; ++p)
+                    wmax = fmaxf(wmax, lg[p]);
+                float s2 = 0.f;
+                for (int p = 0; p < P; ++p)
+                    s2 += expf(lg[p] - wmax);
+                wsum_inv = 1.f / s2;
             }
+            rac_f4 at = {0.f, 0.f, 0.f, 0.f};
+            for (int p0 = 0; p0 < P; p0 += 4) {
+                rac_f4 v[4][4];
+                float tw[4][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                at.x += tw[k][0] * v[k][0].x + tw[k][1] * v[k][1].x + tw[k][2] * v[k][2].x + tw[k][3] * v[k][3].x;
-                at.y += tw[k][0] * v[k][0].y + tw[k][1] * v[k][1].y + tw[k][2] * v[k][2].y + tw[k][3] * v[k][3].y;
-                at.z += tw[k][0] * v[k][0].z + tw[k][1] * v[k][1].z + tw[k][2] * v[k][2].z + tw[k][3] * v[k][3].z;
-                at.w += tw[k][0] * v[k][0].w + tw[k][1] * v[k][1].w + tw[k][2] * v[k][2].w + tw[k][3] * v[k][3].w;
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + u;
+                    const bool act = p < P;
+                    const int pp = act ? p : P - 1;
+                    const float x = lp[pp * 2], y = lp[pp * 2 + 1];
+                    float wgt = a.B > 1 ? expf(lg[pp] - wmax) * wsum_inv : ap[pp];
+                    wgt = act ? wgt : 0.f;
+                    const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
+                    const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                    const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
+                    const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+                    v[u][0] = bev_tap(base, (long)h_low * W + w_low, stride, t_ok && l_ok);
+                    v[u][1] = bev_tap(base, (long)h_low * W + w_high, stride, t_ok && r_ok);
+                    v[u][2] = bev_tap(base, (long)h_high * W + w_low, stride, b_ok && l_ok);
+                    v[u][3] = bev_tap(base, (long)h_high * W + w_high, stride, b_ok && r_ok);
+                    tw[u][0] = hh * hw * wgt;
+                    tw[u][1] = hh * lw * wgt;
+                    tw[u][2] = lh * hw * wgt;
+                    tw[u][3] = lh * lw * wgt;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    at.x += tw[u][0] * v[u][0].x + tw[u][1] * v[u][1].x + tw[u][2] * v[u][2].x + tw[u][3] * v[u][3].x;
+                    at.y += tw[u][0] * v[u][0].y + tw[u][1] * v[u][1].y + tw[u][2] * v[u][2].y + tw[u][3] * v[u][3].y;
+                    at.z += tw[u][0] * v[u][0].z + tw[u][1] * v[u][1].z + tw[u][2] * v[u][2].z + tw[u][3] * v[u][3].z;
+                    at.w += tw[u][0] * v[u][0].w + tw[u][1] * v[u][1].w + tw[u][2] * v[u][2].w + tw[u][3] * v[u][3].w;
+                }
             }
+            const float fw = sq[k * T + t];
+            acc.x += at.x * fw;
+            acc.y += at.y * fw;
+            acc.z += at.z * fw;
+            acc.w += at.w * fw;
         }
-        const float fw = sq[grp * T + t];
-        acc.x += at.x * fw;
-        acc.y += at.y * fw;
-        acc.z += at.z * fw;
-        acc.w += at.w * fw;
     }
-    *reinterpret_cast<rac_f4 *>(a.out + ((size_t)b * per_b + it) * 64 + c4 * 4) = acc;
+    // phase D: fixed-order sum of the four frame subsets (deterministic, no atomics)
+    *reinterpret_cast<rac_f4 *>(spart + (k * BEV_TS + ts) * 64 + c4 * 4) = acc;
+    __syncthreads();
+    if (live && ts == 0) {
+        rac_f4 o = acc;
+#pragma unroll
+        for (int u = 1; u < BEV_TS; ++u) {
+            const rac_f4 pz = *reinterpret_cast<const rac_f4 *>(spart + (k * BEV_TS + u) * 64 + c4 * 4);
+            o.x += pz.x; o.y += pz.y; o.z += pz.z; o.w += pz.w;
+        }
+        *reinterpret_cast<rac_f4 *>(a.out + ((size_t)b * per_b + it) * 64 + c4 * 4) = o;
+    }
 }
 
-extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float *offsets,
+extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float *box_table,
+                                    const float *offsets,
                                     const float *ray_logits, const float *scale_logits, const float *queue_logits,
                                     const float *time_diff, float *out, float *loc_out, int ld_off, int ld_ray,
                                     int ld_scale, int ld_queue, int B, int T, int Q, int heads,
@@ -224,15 +282,18 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
                   "rac_bev_sampling_fwd: bad sizes B=%d T=%d Q=%d heads=%d NP=%d D=%d H=%d W=%d", B, T, Q, heads, NP, D, H, W);
     RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_bev_sampling_fwd: dtype %d", dtype);
     const int P = NP * D;
-    const size_t lds = ((size_t)BEV_ITEMS * T * P * 2 + (size_t)BEV_ITEMS * P + (size_t)BEV_ITEMS * T) * sizeof(float);
+    const size_t lds = ((size_t)BEV_GI * T * P * 2 + (size_t)BEV_GI * P + (size_t)BEV_GI * T + (size_t)BEV_GI * P * 2 +
+                        (size_t)BEV_GI * BEV_MAX_DEPTH + (size_t)BEV_GI * BEV_TS * 64) * sizeof(float);
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_bev_sampling_fwd: T*P=%d too large for the LDS staging", T * P);
     if (B == 0 || Q == 0)
         return 0;
+    RAC_CHECK_ARG(box_table != nullptr, "rac_bev_sampling_fwd: box_table is null (run rac_box_prep_fwd first)");
+    RAC_CHECK_ARG(P <= 128 && heads * D <= 64, "rac_bev_sampling_fwd: P=%d / heads*D=%d exceed the workgroup's staging roles", P, heads * D);
     RAC_CHECK_ARG(value && query_bbox && offsets && ray_logits && scale_logits && queue_logits && time_diff && out &&
                       pc_range && depth_base,
                   "rac_bev_sampling_fwd: null pointer");
     BevArgs a;
-    a.value = value; a.qbox = query_bbox; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
+    a.value = value; a.qbox = query_bbox; a.box = box_table; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
     a.queue = queue_logits; a.time_diff = time_diff; a.out = out; a.loc_out = loc_out;
     for (int i = 0; i < BEV_MAX_DEPTH; ++i)
         a.depth_base[i] = i < D ? depth_base[i] : 0.f;
@@ -241,7 +302,7 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
     a.d_region = d_region;
     a.B = B; a.T = T; a.Q = Q; a.heads = heads; a.NP = NP; a.D = D; a.P = P; a.H = H; a.W = W;
     a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale; a.ld_queue = ld_queue;
-    a.blocks_per_b = (Q * heads + BEV_ITEMS - 1) / BEV_ITEMS;
+    a.blocks_per_b = (Q * heads + BEV_GI - 1) / BEV_GI;
     const int nb = B * a.blocks_per_b;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RAC_F32)

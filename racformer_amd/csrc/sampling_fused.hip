@@ -33,6 +33,7 @@ struct S4dArgs {
     int H[RAC_MAX_LEVELS];
     int W[RAC_MAX_LEVELS];
     const float *qbox;       // [B,Q,10]
+    const float *box;        // [B,Q,8] from rac_box_prep_fwd (cx,cy,cz,w,l,h,cos,sin)
     const float *off;        // [B,Q,G*P*3]
     const float *ray;        // [B,Q,D]
     const float *scale;      // [B,Q,G,T,P,L] logits
@@ -56,18 +57,14 @@ __device__ __forceinline__ void s4d_keypoint(const S4dArgs &a, const float *sl2i
                                              int p, float *loc3, float *wl)
 {
     const float *qb = a.qbox + ((size_t)b * a.Q + q) * 10;
-    const float sx = a.pc[3] - a.pc[0], sy = a.pc[4] - a.pc[1], sz = a.pc[5] - a.pc[2];
-    // theta_d2xy (clamped) + decode_bbox
-    const float ang0 = qb[0] * S4D_TWO_PI;
-    const float rad0 = qb[1] * 65.0f;
-    const float xn0 = fminf(fmaxf((51.2f + rad0 * cosf(ang0)) / 102.4f, 0.f), 1.f);
-    const float yn0 = fminf(fmaxf((51.2f + rad0 * sinf(ang0)) / 102.4f, 0.f), 1.f);
-    const float cx = xn0 * sx + a.pc[0], cy = yn0 * sy + a.pc[1], cz = qb[2] * sz + a.pc[2];
-    const float yaw = atan2f(qb[6], qb[7]);
-    const float cs = cosf(yaw), sn = sinf(yaw);
+    const float sx = a.pc[3] - a.pc[0], sy = a.pc[4] - a.pc[1];
+    // per-query constants (decode_bbox(theta_d2xy(box))) come from the box table
+    const float *bt = a.box + ((size_t)b * a.Q + q) * 8;
+    const float cx = bt[0], cy = bt[1], cz = bt[2];
+    const float cs = bt[6], sn = bt[7];
     // make_sample_points: xyz + R_z(yaw) (wlh * offset)
     const float *o = a.off + ((size_t)b * a.Q + q) * a.ld_off + ((size_t)g * a.P + p) * 3;
-    const float dx = expf(qb[3]) * o[0], dy = expf(qb[4]) * o[1], dz = expf(qb[5]) * o[2];
+    const float dx = bt[3] * o[0], dy = bt[4] * o[1], dz = bt[5] * o[2];
     float px = cx + (dx * cs - dy * sn);
     float py = cy + (dx * sn + dy * cs);
     const float pz = cz + dz;
@@ -230,6 +227,7 @@ __global__ __launch_bounds__(256, 4) void sampling4d_c64_kernel(const S4dArgs a)
 }
 
 extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox,
+                                  const float *box_table,
                                   const float *offsets, const float *ray_logits, const float *scale_logits,
                                   const float *time_diff, const float *lidar2img, float *out, float *loc_out,
                                   float *w_out, int ld_off, int ld_ray, int ld_scale, int B, int T, int N, int G, int Q, int NP,
@@ -247,6 +245,7 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
     RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_sampling4d_fwd: dtype %d", dtype);
     if (B == 0 || Q == 0)
         return 0;
+    RAC_CHECK_ARG(box_table != nullptr, "rac_sampling4d_fwd: box_table is null (run rac_box_prep_fwd first)");
     RAC_CHECK_ARG(feats && hw && query_bbox && offsets && ray_logits && scale_logits && time_diff && lidar2img &&
                       out && pc_range && depth_base,
                   "rac_sampling4d_fwd: null pointer");
@@ -263,7 +262,7 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
         a.H[l] = hw[2 * l];
         a.W[l] = hw[2 * l + 1];
     }
-    a.qbox = query_bbox; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
+    a.qbox = query_bbox; a.box = box_table; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
     a.time_diff = time_diff; a.l2i = lidar2img; a.out = out; a.loc_out = loc_out; a.w_out = w_out;
     for (int i = 0; i < S4D_MAX_DEPTH; ++i)
         a.depth_base[i] = i < D ? depth_base[i] : 0.f;

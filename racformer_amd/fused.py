@@ -26,9 +26,20 @@ def _rows(t, width, what):
     return _lib.ptr(t), int(t.stride(-2))
 
 
+def box_prep(query_bbox, pc_range):
+    """[B,Q,10] polar boxes -> [B,Q,8] (cx,cy,cz,w,l,h,cos yaw,sin yaw), once per decoder layer."""
+    _lib.require_gpu(query_bbox, what="box_prep")
+    table = torch.empty(query_bbox.shape[:-1] + (8,), device=query_bbox.device, dtype=torch.float32)
+    pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    rc = _lib.lib().rac_box_prep_fwd(_lib.ptr(query_bbox), _lib.ptr(table), query_bbox.numel() // 10, pc,
+                                     _lib.stream_ptr())
+    _lib.check(rc, "rac_box_prep_fwd")
+    return table
+
+
 def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, time_diff, lidar2img,
                      num_frames, num_groups, num_points, depth_num, pc_range, d_region, image_h, image_w,
-                     eps=1e-5, debug=False):
+                     eps=1e-5, debug=False, box_table=None):
     """-> [B,Q,G,T*P,C] (and, with debug=True, the kernel's own locations [S,Q,P,3] and softmaxed scale
     weights [S,Q,P,L] for parity checks)."""
     feats = list(mlvl_feats)
@@ -43,6 +54,8 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
     p_off, ld_off = _rows(offsets, G * P * 3, "sampling4d_fused(offsets)")
     p_ray, ld_ray = _rows(ray_logits, D, "sampling4d_fused(ray_logits)")
     p_sc, ld_sc = _rows(scale_logits, G * T * P * L, "sampling4d_fused(scale_logits)")
+    if box_table is None:
+        box_table = box_prep(query_bbox, pc_range)
     out = torch.empty(B, Q, G, T * P, C, device=query_bbox.device, dtype=torch.float32)
     loc_out = w_out = None
     capture = _lib.timer is not None and getattr(_lib.timer, "capture_inputs", False)
@@ -57,7 +70,7 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
     if ev:
         ev[0].record()
     rc = _lib.lib().rac_sampling4d_fwd(
-        ptrs, hw, L, _lib.ptr(query_bbox), p_off, p_ray, p_sc, _lib.ptr(time_diff), _lib.ptr(lidar2img),
+        ptrs, hw, L, _lib.ptr(query_bbox), _lib.ptr(box_table), p_off, p_ray, p_sc, _lib.ptr(time_diff), _lib.ptr(lidar2img),
         _lib.ptr(out), _lib.ptr(loc_out) if debug else None, _lib.ptr(w_out) if debug else None,
         ld_off, ld_ray, ld_sc, B, T, N, G, Q, NP, D, C, pc, _depth_base(float(d_region), D), float(d_region),
         float(image_h), float(image_w), float(eps), _lib.dtype_code(feats[0]), _lib.stream_ptr())
@@ -70,7 +83,7 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
 
 
 def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits, queue_logits, time_diff,
-                       num_frames, num_heads, num_points, depth_num, pc_range, d_region, debug=False):
+                       num_frames, num_heads, num_points, depth_num, pc_range, d_region, debug=False, box_table=None):
     """value [B*T, H*W, heads, 64] -> [B,Q,heads*64] (frame-fused, before output_proj)."""
     _lib.require_gpu(value, query_bbox, time_diff, what="bev_sampling_fused")
     B, Q, _ = query_bbox.shape
@@ -83,6 +96,8 @@ def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits,
     p_ray, ld_ray = _rows(ray_logits, D, "bev_sampling_fused(ray_logits)")
     p_sc, ld_sc = _rows(scale_logits, Hn * P, "bev_sampling_fused(scale_logits)")
     p_qu, ld_qu = _rows(queue_logits, T, "bev_sampling_fused(queue_logits)")
+    if box_table is None:
+        box_table = box_prep(query_bbox, pc_range)
     out = torch.empty(B, Q, Hn * 64, device=query_bbox.device, dtype=torch.float32)
     loc_out = torch.empty(B, Q, Hn, T, P, 2, device=out.device, dtype=torch.float32) if debug else None
     pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
@@ -90,7 +105,7 @@ def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits,
     if ev:
         ev[0].record()
     rc = _lib.lib().rac_bev_sampling_fwd(
-        _lib.ptr(value), _lib.ptr(query_bbox), p_off, p_ray, p_sc, p_qu, _lib.ptr(time_diff), _lib.ptr(out),
+        _lib.ptr(value), _lib.ptr(query_bbox), _lib.ptr(box_table), p_off, p_ray, p_sc, p_qu, _lib.ptr(time_diff), _lib.ptr(out),
         _lib.ptr(loc_out) if debug else None, ld_off, ld_ray, ld_sc, ld_qu, B, T, Q, Hn, NP, D, H, W, 64, pc,
         _depth_base(float(d_region), D), float(d_region), _lib.dtype_code(value), _lib.stream_ptr())
     if ev:

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import bev_sampling_fused, mixing_fused, sampling4d_fused, sasa_fused
+from .fused import bev_sampling_fused, box_prep, mixing_fused, sampling4d_fused, sasa_fused
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -208,7 +208,8 @@ class RaCFormerSampling(nn.Module):
         points, sw = self.keypoints(query_ray, query_feat, img_metas[0]["time_diff"], d_region)
         return sampling_4d(points, mlvl_feats, sw, img_metas[0]["lidar2img"], image_h, image_w)
 
-    def forward(self, query_ray, query_feat, mlvl_feats, img_metas, d_region=0.1, linear_out=None, debug=False):
+    def forward(self, query_ray, query_feat, mlvl_feats, img_metas, d_region=0.1, linear_out=None, debug=False,
+                box_table=None):
         """One fused HIP kernel (rac_sampling4d_fwd).  ``linear_out`` = (offsets, ray logits, scale
         logits) if the caller already ran the three Linears as part of a wider GEMM."""
         image_h, image_w, _ = img_metas[0]["img_shape"][0]
@@ -218,7 +219,8 @@ class RaCFormerSampling(nn.Module):
         off, ray, sc = linear_out
         return sampling4d_fused(mlvl_feats, query_ray.contiguous(), off, ray, sc, img_metas[0]["time_diff"],
                                 img_metas[0]["lidar2img"], self.num_frames, self.num_groups, self.num_points,
-                                self.depth_num, self.pc_range, d_region, image_h, image_w, debug=debug)
+                                self.depth_num, self.pc_range, d_region, image_h, image_w, debug=debug,
+                                box_table=box_table)
 
 
 def sampling_4d(sample_points, mlvl_feats, scale_weights, lidar2img, image_h, image_w, aggregate=True,
@@ -438,14 +440,15 @@ class BEVSampling(nn.Module):
         loc, sw = self.keypoints(query_ray, query_feat, time_diff, d_region)
         return self.attention.attend(query_feat, value, loc, sw, hw)
 
-    def attend_prepared(self, query_ray, query_feat, value, hw, time_diff, d_region, linear_out=None):
+    def attend_prepared(self, query_ray, query_feat, value, hw, time_diff, d_region, linear_out=None, box_table=None):
         """One fused HIP kernel (rac_bev_sampling_fwd) + output_proj + identity."""
         if linear_out is None:
             linear_out = (self.sampling_offset(query_feat), self.ray_points_offset(query_feat),
                           self.scale_weights(query_feat), self.attention.bev_queue_weight(query_feat))
         off, ray, sc, qu = linear_out
         fused = bev_sampling_fused(value, hw, query_ray.contiguous(), off, ray, sc, qu, time_diff, self.num_frames,
-                                   self.num_heads, self.num_points, self.depth_num, self.pc_range, d_region)
+                                   self.num_heads, self.num_points, self.depth_num, self.pc_range, d_region,
+                                   box_table=box_table)
         return self.attention.output_proj(fused) + query_feat
 
     def forward(self, query_ray, query_feat, bev_feats, img_metas, d_region=0.1):
@@ -610,12 +613,14 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         query_feat = self.norm1(sa)
         if self.fused:
             lin = F.linear(query_feat, prepared["wide_w"], prepared["wide_b"]).split(prepared["wide_widths"], dim=-1)
-            radar_raw = self.sampling_radar_bev.attend_prepared(query_bbox, query_feat, prepared["radar_value"],
-                                                                prepared["radar_hw"], time_diff, d_region, lin[3:7])
-            lss_raw = self.sampling_lss_bev.attend_prepared(query_bbox, query_feat, prepared["lss_value"],
-                                                            prepared["lss_hw"], time_diff, d_region, lin[7:11])
-            sampled_feat = self.sampling(query_bbox, query_feat, mlvl_feats, img_metas, d_region=d_region,
-                                         linear_out=lin[0:3])
+            qb = query_bbox.contiguous()
+            table = box_prep(qb, self.pc_range)       # decode_bbox(theta_d2xy(.)) once for the 3 sampling kernels
+            radar_raw = self.sampling_radar_bev.attend_prepared(qb, query_feat, prepared["radar_value"],
+                                                                prepared["radar_hw"], time_diff, d_region, lin[3:7], table)
+            lss_raw = self.sampling_lss_bev.attend_prepared(qb, query_feat, prepared["lss_value"],
+                                                            prepared["lss_hw"], time_diff, d_region, lin[7:11], table)
+            sampled_feat = self.sampling(qb, query_feat, mlvl_feats, img_metas, d_region=d_region,
+                                         linear_out=lin[0:3], box_table=table)
         else:
             radar_raw = self.sampling_radar_bev.attend_prepared_unfused(
                 query_bbox, query_feat, prepared["radar_value"], prepared["radar_hw"], time_diff, d_region)

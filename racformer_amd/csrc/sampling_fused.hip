@@ -25,6 +25,12 @@
 #include "rac_common.h"
 
 #define S4D_ROWS 4
+#ifndef S4D_LB
+#define S4D_LB 4 /* levels per load batch (see the gather loop) */
+#endif
+#ifndef S4D_WPS
+#define S4D_WPS 4 /* waves per SIMD the register allocator must allow */
+#endif
 #define S4D_MAX_DEPTH 16
 #define S4D_MAX_CAMS 16
 
@@ -135,7 +141,7 @@ __device__ __forceinline__ rac_f4 s4d_tap(const FT *base, int h, int w, int W, b
 }
 
 template <typename FT, int L>
-__global__ __launch_bounds__(256, 4) void sampling4d_c64_kernel(const S4dArgs a)
+__global__ __launch_bounds__(256, S4D_WPS) void sampling4d_c64_kernel(const S4dArgs a)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x;
@@ -187,39 +193,50 @@ __global__ __launch_bounds__(256, 4) void sampling4d_c64_kernel(const S4dArgs a)
         const float lu = lp[0], lv = lp[1];
         const int view = (int)lp[2];
 
-        rac_f4 v[L][4];
-        float tw[L][4];
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int H = a.H[l], W = a.W[l];
-            const float h_im = lv * (float)(H - 1);
-            const float w_im = lu * (float)(W - 1);
-            const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-            const float hf = floorf(h_im), wf = floorf(w_im);
-            const int h_low = (int)hf, w_low = (int)wf;
-            const int h_high = h_low + 1, w_high = w_low + 1;
-            const float lh = h_im - hf, lw = w_im - wf;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            const FT *base = (const FT *)a.feat[l] + ((size_t)s * a.N + view) * H * W * 64 + c4 * 4;
-            const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
-            const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-            v[l][0] = s4d_tap(base, h_low, w_low, W, t_ok && l_ok);
-            v[l][1] = s4d_tap(base, h_low, w_high, W, t_ok && r_ok);
-            v[l][2] = s4d_tap(base, h_high, w_low, W, b_ok && l_ok);
-            v[l][3] = s4d_tap(base, h_high, w_high, W, b_ok && r_ok);
-            tw[l][0] = hh * hw;
-            tw[l][1] = hh * lw;
-            tw[l][2] = lh * hw;
-            tw[l][3] = lh * lw;
-        }
         rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        // levels are processed LB at a time: LB*4 tap loads in flight per lane.  LB trades loads in
+        // flight per wave against registers (occupancy): S4D_LB=2 -> ~80 VGPR, 6 waves/SIMD.
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const float wl = wp[l];
-            acc.x += (tw[l][0] * v[l][0].x + tw[l][1] * v[l][1].x + tw[l][2] * v[l][2].x + tw[l][3] * v[l][3].x) * wl;
-            acc.y += (tw[l][0] * v[l][0].y + tw[l][1] * v[l][1].y + tw[l][2] * v[l][2].y + tw[l][3] * v[l][3].y) * wl;
-            acc.z += (tw[l][0] * v[l][0].z + tw[l][1] * v[l][1].z + tw[l][2] * v[l][2].z + tw[l][3] * v[l][3].z) * wl;
-            acc.w += (tw[l][0] * v[l][0].w + tw[l][1] * v[l][1].w + tw[l][2] * v[l][2].w + tw[l][3] * v[l][3].w) * wl;
+        for (int l0 = 0; l0 < L; l0 += S4D_LB) {
+            rac_f4 v[S4D_LB][4];
+            float tw[S4D_LB][4];
+#pragma unroll
+            for (int k = 0; k < S4D_LB; ++k) {
+                const int l = l0 + k;
+                if (l < L) {
+                    const int H = a.H[l], W = a.W[l];
+                    const float h_im = lv * (float)(H - 1);
+                    const float w_im = lu * (float)(W - 1);
+                    const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int h_low = (int)hf, w_low = (int)wf;
+                    const int h_high = h_low + 1, w_high = w_low + 1;
+                    const float lh = h_im - hf, lw = w_im - wf;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const FT *base = (const FT *)a.feat[l] + ((size_t)s * a.N + view) * H * W * 64 + c4 * 4;
+                    const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
+                    const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+                    v[k][0] = s4d_tap(base, h_low, w_low, W, t_ok && l_ok);
+                    v[k][1] = s4d_tap(base, h_low, w_high, W, t_ok && r_ok);
+                    v[k][2] = s4d_tap(base, h_high, w_low, W, b_ok && l_ok);
+                    v[k][3] = s4d_tap(base, h_high, w_high, W, b_ok && r_ok);
+                    tw[k][0] = hh * hw;
+                    tw[k][1] = hh * lw;
+                    tw[k][2] = lh * hw;
+                    tw[k][3] = lh * lw;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < S4D_LB; ++k) {
+                const int l = l0 + k;
+                if (l < L) {
+                    const float wl = wp[l];
+                    acc.x += (tw[k][0] * v[k][0].x + tw[k][1] * v[k][1].x + tw[k][2] * v[k][2].x + tw[k][3] * v[k][3].x) * wl;
+                    acc.y += (tw[k][0] * v[k][0].y + tw[k][1] * v[k][1].y + tw[k][2] * v[k][2].y + tw[k][3] * v[k][3].y) * wl;
+                    acc.z += (tw[k][0] * v[k][0].z + tw[k][1] * v[k][1].z + tw[k][2] * v[k][2].z + tw[k][3] * v[k][3].z) * wl;
+                    acc.w += (tw[k][0] * v[k][0].w + tw[k][1] * v[k][1].w + tw[k][2] * v[k][2].w + tw[k][3] * v[k][3].w) * wl;
+                }
+            }
         }
         if (act)
             *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = acc;

@@ -21,6 +21,9 @@
  *   rac_box_prep_fwd  <- decode_bbox(theta_d2xy_coods(.)) models/bbox/utils.py:66-90 (shared prologue)
  *   rac_sampling4d_fwd<- RaCFormerSampling.inner_forward + sampling_4d + msmv op, fused
  *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
+ *   rac_add_ln_fwd    <- residual add + nn.LayerNorm (+ReLU) groups, models/racformer_transformer.py:170-258
+ *   rac_refine_fwd    <- refine_bbox + velocity scaling + theta_d2xy_coods of the outputs
+ *                        models/racformer_transformer.py:230-236,265-269,134
  *   rac_mixing_fwd    <- AdaptiveMixing.inner_forward's matmul / layer_norm / relu chain
  *                        models/racformer_transformer.py:589-603
  *   rac_sasa_fwd      <- ScaleAdaptiveSelfAttention.inner_forward's mask + attention product
@@ -132,6 +135,22 @@ int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float
  *   out : device f32 [B,Q,heads*dim];  pc_range: HOST (6).  dim must be 32. */
 int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, float *out, int ld_qkv,
                  int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream);
+
+/* Row-wise  out = [relu]( LayerNorm( sum_{s<num_partials} a[s] + residual + bias ) * gamma + beta ).
+ * Replaces the add / bias / split-K reduce + nn.LayerNorm (+ ReLU) launch groups of the decoder layer
+ * (models/racformer_transformer.py:170-177, 199-205, 246-258).  a: device f32 [num_partials][rows][dim]
+ * (partial s at a + s*partial_stride); residual [rows][dim], bias [dim]: optional (NULL); dim % 4 == 0, <= 1024. */
+int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, const float *residual,
+                   const float *bias, const float *gamma, const float *beta, float *out, int rows, int dim,
+                   float eps, int relu, void *stream);
+
+/* Box refinement tail of a decoder layer: refine_bbox + velocity / time_diff + theta_d2xy of the emitted
+ * boxes (models/racformer_transformer.py:230-236, :265-269, :134; models/bbox/utils.py:82-90).
+ *   proposal [B*Q,10] (this layer's input boxes), delta [B*Q,10] (reg_branch output),
+ *   time_diff_safe [B,T] (time_diff with values < 1e-5 replaced by 1)  ->
+ *   bbox_pred [B*Q,10] (polar, next layer's input), bbox_xy [B*Q,10] (normalised xy, the layer's output). */
+int rac_refine_fwd(const float *proposal, const float *delta, const float *time_diff_safe, float *bbox_pred,
+                   float *bbox_xy, int B, int Q, int T, float num_ray, void *stream);
 
 /* AdaptiveMixing core on the matrix cores (exact-fp32 MFMA): per (query, group) item
  *   Y = relu(LN_{[P,64]}(x @ M)),  Z = relu(LN_{[128,64]}(S @ Y))

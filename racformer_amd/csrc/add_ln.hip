@@ -1,0 +1,93 @@
+// add_ln.hip -- residual / split-K-sum / bias + LayerNorm (+ ReLU) as one row-wise kernel (gfx950).
+//
+// The decoder layer applies LayerNorm(256) ten times per layer, always right after an add
+// (x + attn, x + proj, f + ffn, ...; models/racformer_transformer.py:170-177,199-205,246-258) or
+// followed by a ReLU (position encoder, cls branch).  In torch each is 2-4 launches; here
+//     out = [relu]( LN( sum_s a[s] + residual + bias ) * gamma + beta )
+// is one launch: one wave64 per row, 16-byte loads, two-pass mean / variance in registers.
+#include "rac_common.h"
+
+#define ALN_MAX_V 4 /* float4 per lane: dim <= 1024 */
+
+__device__ __forceinline__ float aln_wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a, int S, long pstride,
+                                                     const float *__restrict__ residual, const float *__restrict__ bias,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     float *__restrict__ out, int rows, int dim, float eps, int relu)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows)
+        return;
+    const int nv = dim >> 2;  // float4 per row
+    rac_f4 x[ALN_MAX_V];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < ALN_MAX_V; ++k) {
+        const int c = lane + 64 * k;
+        x[k] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            rac_f4 v = rac_ld4(a + (size_t)row * dim + c * 4);
+            for (int s = 1; s < S; ++s) {
+                const rac_f4 w = rac_ld4(a + (size_t)s * pstride + (size_t)row * dim + c * 4);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            if (bias) {
+                const rac_f4 w = rac_ld4(bias + c * 4);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            if (residual) {
+                const rac_f4 w = rac_ld4(residual + (size_t)row * dim + c * 4);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            x[k] = v;
+            sum += (v.x + v.y) + (v.z + v.w);
+        }
+    }
+    const float mean = aln_wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < ALN_MAX_V; ++k)
+        if (lane + 64 * k < nv) {
+            const float d0 = x[k].x - mean, d1 = x[k].y - mean, d2 = x[k].z - mean, d3 = x[k].w - mean;
+            sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    const float rstd = 1.f / sqrtf(aln_wave_sum(sq) / (float)dim + eps);
+#pragma unroll
+    for (int k = 0; k < ALN_MAX_V; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nv) {
+            const rac_f4 g = rac_ld4(gamma + c * 4), b = rac_ld4(beta + c * 4);
+            rac_f4 y;
+            y.x = (x[k].x - mean) * rstd * g.x + b.x;
+            y.y = (x[k].y - mean) * rstd * g.y + b.y;
+            y.z = (x[k].z - mean) * rstd * g.z + b.z;
+            y.w = (x[k].w - mean) * rstd * g.w + b.w;
+            if (relu) {
+                y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+            }
+            *reinterpret_cast<rac_f4 *>(out + (size_t)row * dim + c * 4) = y;
+        }
+    }
+}
+
+extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, const float *residual,
+                              const float *bias, const float *gamma, const float *beta, float *out, int rows, int dim,
+                              float eps, int relu, void *stream)
+{
+    RAC_CHECK_ARG(rows >= 0 && dim >= 4 && dim % 4 == 0 && dim <= 256 * ALN_MAX_V, "rac_add_ln_fwd: dim=%d (multiple of 4, <= %d)", dim, 256 * ALN_MAX_V);
+    RAC_CHECK_ARG(num_partials >= 1, "rac_add_ln_fwd: num_partials=%d", num_partials);
+    if (rows == 0)
+        return 0;
+    RAC_CHECK_ARG(a && gamma && beta && out, "rac_add_ln_fwd: null pointer");
+    hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, num_partials,
+                       (long)partial_stride, residual, bias, gamma, beta, out, rows, dim, eps, relu);
+    return rac_launch_status("rac_add_ln_fwd");
+}

@@ -154,3 +154,36 @@ def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5):
         ev[1].record()
     _lib.check(rc, "rac_mixing_fwd")
     return out
+
+
+def refine_fused(proposal, delta, time_diff_safe, num_ray):
+    """refine_bbox + velocity / time_diff + theta_d2xy in one launch.
+    -> (bbox_pred [B,Q,10] polar, bbox_xy [B,Q,10] normalised xy)."""
+    proposal, delta = proposal.contiguous(), delta.contiguous()
+    _lib.require_gpu(proposal, delta, time_diff_safe, what="refine_fused")
+    B, Q, _ = proposal.shape
+    pred, xy = torch.empty_like(proposal), torch.empty_like(proposal)
+    rc = _lib.lib().rac_refine_fwd(_lib.ptr(proposal), _lib.ptr(delta), _lib.ptr(time_diff_safe), _lib.ptr(pred),
+                                   _lib.ptr(xy), B, Q, time_diff_safe.shape[1], float(num_ray), _lib.stream_ptr())
+    _lib.check(rc, "rac_refine_fwd")
+    return pred, xy
+
+
+def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1):
+    """[relu](LayerNorm(sum_s a[s] + residual + bias)) with ``norm`` an nn.LayerNorm; a is [..., dim]
+    (or [S, ..., dim] with num_partials=S).  One launch."""
+    a = a.contiguous()
+    _lib.require_gpu(a, what="add_ln")
+    dim = a.shape[-1]
+    shape = a.shape[1:] if num_partials > 1 else a.shape
+    if residual is not None and residual.numel() == a.numel() // num_partials:
+        shape = residual.shape
+    rows = a.numel() // dim // num_partials
+    if residual is not None:
+        residual = residual.contiguous()
+    out = torch.empty(shape, device=a.device, dtype=torch.float32)
+    rc = _lib.lib().rac_add_ln_fwd(_lib.ptr(a), num_partials, rows * dim, _lib.ptr(residual) if residual is not None else None,
+                                   _lib.ptr(bias) if bias is not None else None, _lib.ptr(norm.weight), _lib.ptr(norm.bias),
+                                   _lib.ptr(out), rows, dim, float(norm.eps), int(relu), _lib.stream_ptr())
+    _lib.check(rc, "rac_add_ln_fwd")
+    return out

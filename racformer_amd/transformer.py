@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import bev_sampling_fused, box_prep, mixing_fused, sampling4d_fused, sasa_fused
+from .fused import add_ln, bev_sampling_fused, box_prep, mixing_fused, refine_fused, sampling4d_fused, sasa_fused
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -489,12 +489,24 @@ class AdaptiveMixing(nn.Module):
         S = self.SPLIT_K if K % self.SPLIT_K == 0 else 1
         return w.view(N, S, K // S).permute(1, 0, 2).contiguous()
 
+    def fused_supported(self, x):
+        B, Q, G, P, C = x.shape
+        return x.is_cuda and C == 64 and self.eff_out_dim == 64 and self.out_points == 128 and P <= 96
+
+    def out_proj_partials(self, x, query, out_proj_split):
+        """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
+        out_proj.  Returns the S partial products [S, B*Q, query_dim]; their sum + out_proj.bias + query
+        is inner_forward's result (the caller folds that sum into its LayerNorm kernel)."""
+        B, Q, G, P, C = x.shape
+        out = mixing_fused(x.contiguous(), self.parameter_generator(query), P, G, self.out_points)
+        S_, N, k = out_proj_split.shape
+        return torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
+
     def forward(self, x, query, out_proj_split=None):
         B, Q, G, P, C = x.shape
         assert G == self.n_groups and P == self.in_points and C == self.eff_in_dim
         params = self.parameter_generator(query)
-        if out_proj_split is not None and x.is_cuda and C == 64 and self.eff_out_dim == 64 and \
-                self.out_points == 128 and P <= 96:
+        if out_proj_split is not None and self.fused_supported(x):
             # fused plan: one MFMA kernel for both mixings + norms + ReLUs, split-K out_proj
             out = mixing_fused(x.contiguous(), params, P, G, self.out_points)
             S_, N, k = out_proj_split.shape
@@ -600,10 +612,64 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
                     wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=self.mixing.split_out_proj(),
                     sasa_w=self.self_attn.wide_in_proj())
 
+    def forward_fused(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None):
+        """The layer as a chain of library GEMMs and hand-written HIP kernels only: every LayerNorm is fused
+        with the add / split-K reduction / bias / ReLU around it (rac_add_ln_fwd), the box tail is one
+        kernel (rac_refine_fwd).  Same arithmetic as ``forward`` (racformer_transformer.py:239-279)."""
+        meta = img_metas[0]
+        time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
+        qb = query_bbox.contiguous()
+        pe = self.position_encoder
+        h = add_ln(pe[0](qb[..., :3]), pe[1], relu=True)
+        query_pos = add_ln(pe[3](h), pe[4], relu=True)
+        x = query_feat + query_pos
+        # scale-adaptive self-attention
+        p = self.self_attn.attention.attn
+        E = self.embed_dims
+        lin = F.linear(x, prepared["sasa_w"][0], prepared["sasa_w"][1])
+        attn = p.out_proj(sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], qb, self.self_attn.num_heads, self.pc_range))
+        x1 = add_ln(attn, self.norm1, residual=x)
+        # the three sampling modules: one wide GEMM, one box table, three fused kernels
+        lin = F.linear(x1, prepared["wide_w"], prepared["wide_b"]).split(prepared["wide_widths"], dim=-1)
+        table = box_prep(qb, self.pc_range)
+        rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
+        r_off, r_ray, r_sc, r_qu = lin[3:7]
+        l_off, l_ray, l_sc, l_qu = lin[7:11]
+        r_proj = rb.attention.output_proj(bev_sampling_fused(
+            prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff, rb.num_frames,
+            rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region, box_table=table))
+        l_proj = lb.attention.output_proj(bev_sampling_fused(
+            prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff, lb.num_frames,
+            lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region, box_table=table))
+        query_radar_feat = add_ln(r_proj, self.norm_radar_bev, residual=x1)
+        query_lss_feat = add_ln(l_proj, self.norm_lss_bev, residual=x1)
+        sampled_feat = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=lin[0:3],
+                                     box_table=table)
+        # adaptive mixing: split-K partial sums + bias + residual are folded into norm2
+        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"])
+        x2 = add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0])
+        f = add_ln(self.fusion(torch.cat((x2, query_radar_feat, query_lss_feat), dim=-1)), self.norm_fusion)
+        ffn_lin = self.ffn.layers[1](F.relu(self.ffn.layers[0][0](f)))
+        x3 = add_ln(ffn_lin, self.norm3, residual=f)
+        cb = self.cls_branch
+        c = add_ln(cb[0](x3), cb[1], relu=True)
+        c = add_ln(cb[3](c), cb[4], relu=True)
+        cls_score = cb[6](c)
+        bbox_pred, bbox_xy = refine_fused(qb, self.reg_branch(x3), meta["time_diff_safe"], self.num_ray)
+        if stages is not None:
+            stages.update(position_encoder=query_pos, self_attn=x + attn, sampling_radar_bev=r_proj + x1,
+                          sampling_lss_bev=l_proj + x1, sampling=sampled_feat,
+                          mixing=x1 + partials.sum(0).view_as(x1) + self.mixing.out_proj.bias, ffn=f + ffn_lin)
+        self.last_bbox_xy = bbox_xy
+        return x3, cls_score, bbox_pred
+
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
                 layer=0, prepared=None, stages=None):
         if prepared is None:
             prepared = self.prepare(lss_bev_feats, radar_bev_feats)
+        if self.fused and attn_mask is None and query_feat.is_cuda and self.embed_dims == 256 and \
+                self.mixing.in_points <= 96:
+            return self.forward_fused(query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages)
         meta = img_metas[0]
         time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
         query_pos = self.position_encoder(query_bbox[..., :3])
@@ -635,13 +701,18 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         ffn_out = self.ffn(query_feat)
         query_feat = self.norm3(ffn_out)
         cls_score = self.cls_branch(query_feat)
-        bbox_pred = self.refine_bbox(query_bbox, self.reg_branch(query_feat))
-        if time_diff.shape[1] > 1:
-            td = meta["time_diff_safe"][:, 1:2, None]
-            bbox_pred = torch.cat([bbox_pred[..., :8], bbox_pred[..., 8:] / td], dim=-1)
+        if self.fused:
+            bbox_pred, bbox_xy = refine_fused(query_bbox, self.reg_branch(query_feat), meta["time_diff_safe"], self.num_ray)
+        else:
+            bbox_pred = self.refine_bbox(query_bbox, self.reg_branch(query_feat))
+            if time_diff.shape[1] > 1:
+                td = meta["time_diff_safe"][:, 1:2, None]
+                bbox_pred = torch.cat([bbox_pred[..., :8], bbox_pred[..., 8:] / td], dim=-1)
+            bbox_xy = theta_d2xy_coods(bbox_pred)
         if stages is not None:
             stages.update(position_encoder=query_pos, self_attn=sa, sampling_radar_bev=radar_raw,
                           sampling_lss_bev=lss_raw, sampling=sampled_feat, mixing=mixed, ffn=ffn_out)
+        self.last_bbox_xy = bbox_xy   # theta_d2xy_coods(bbox_pred), the per-layer output of the decoder (:134)
         return query_feat, cls_score, bbox_pred
 
 
@@ -718,7 +789,7 @@ class RaCFormerTransformerDecoder(nn.Module):
                 stages_per_layer.append(st)
             query_bbox = bbox_pred.detach()
             cls_scores.append(cls_score)
-            bbox_preds.append(theta_d2xy_coods(bbox_pred))
+            bbox_preds.append(self.decoder_layer.last_bbox_xy)
         return torch.stack(cls_scores), torch.stack(bbox_preds)
 
 

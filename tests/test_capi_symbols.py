@@ -49,7 +49,7 @@ def declared_params():
         for name, params in re.findall(r"\b(rac_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
             kinds = []
             for prm in [x.strip() for x in params.split(",") if x.strip() and x.strip() != "void"]:
-                kinds.append("p" if "*" in prm else ("f" if prm.startswith("float") else "i"))
+                kinds.append("p" if "*" in prm else ("f" if prm.startswith("float") else ("l" if prm.startswith("int64_t") else "i")))
             out[name] = kinds
     return out
 
@@ -58,7 +58,7 @@ def test_python_binding_covers_header(built_lib):
     from racformer_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     assert _lib.lib().rac_abi_version() == 1
-    kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f"}
+    kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f", ctypes.c_int64: "l"}
     for name, kinds in declared_params().items():
         got = [kind[a] for a in _lib.SIGNATURES[name][1]]
         assert got == kinds, f"{name}: ctypes argtypes {got} != header {kinds}"

@@ -109,3 +109,32 @@ def test_mixing_fused(P):
     torch.cuda.synchronize()
     assert (got - unf).abs().max().item() < 2e-4
     assert (got.cpu() - ref).abs().max().item() < 2e-4
+
+
+def test_refine_and_add_ln_kernels():
+    from racformer_amd.fused import add_ln, refine_fused
+    torch.manual_seed(3)
+    B, Q, T = 2, 37, 3
+    prop = torch.rand(B, Q, 10)
+    prop[0, 0, 1:3] = torch.tensor([0.0, 1.0])       # inverse_sigmoid clamps
+    delta = torch.randn(B, Q, 10)
+    td = torch.tensor([[0.0, 0.5, 1.0], [0.0, 1.0, 1.5]])
+    td_safe = td.clone()
+    td_safe[td_safe < 1e-5] = 1.0
+    ref = R.refine_bbox(prop, delta, 150)
+    ref = torch.cat([ref[..., :8], ref[..., 8:] / td_safe[:, 1:2, None]], dim=-1)
+    pred, xy = refine_fused(prop.to(DEV), delta.to(DEV), td_safe.to(DEV), 150)
+    assert (pred.cpu() - ref).abs().max().item() < 1e-5
+    assert (xy.cpu() - R.theta_d2xy(ref)).abs().max().item() < 1e-5
+    for dim, S, relu in ((256, 1, False), (256, 32, True), (512, 3, False), (1024, 1, True)):
+        ln = torch.nn.LayerNorm(dim)
+        torch.nn.init.normal_(ln.weight)
+        torch.nn.init.normal_(ln.bias)
+        a, res, bias = torch.randn(S, 5, 41, dim), torch.randn(5, 41, dim), torch.randn(dim)
+        want = ln(a.sum(0) + res + bias)
+        want = torch.relu(want) if relu else want
+        lg = ln.to(DEV)
+        got = add_ln(a.to(DEV) if S > 1 else a[0].to(DEV), lg, residual=res.to(DEV), bias=bias.to(DEV), relu=relu,
+                     num_partials=S)
+        assert (got.cpu() - want.detach()).abs().max().item() < 2e-5, (dim, S)
+        ln.cpu()

@@ -21,6 +21,8 @@
  *   rac_box_prep_fwd  <- decode_bbox(theta_d2xy_coods(.)) models/bbox/utils.py:66-90 (shared prologue)
  *   rac_sampling4d_fwd<- RaCFormerSampling.inner_forward + sampling_4d + msmv op, fused
  *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
+ *   rac_layer_tail_fwd<- decoder-layer tail (projections, norms, fusion, FFN, branches, refine), one launch
+ *                        models/racformer_transformer.py:249-269
  *   rac_add_ln_fwd    <- residual add + nn.LayerNorm (+ReLU) groups, models/racformer_transformer.py:170-258
  *   rac_refine_fwd    <- refine_bbox + velocity scaling + theta_d2xy_coods of the outputs
  *                        models/racformer_transformer.py:230-236,265-269,134
@@ -135,6 +137,21 @@ int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float
  *   out : device f32 [B,Q,heads*dim];  pc_range: HOST (6).  dim must be 32. */
 int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, float *out, int ld_qkv,
                  int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream);
+
+/* Everything after the three sampling kernels of a decoder layer in one launch (exact-fp32 MFMA row chain):
+ * BEV output projections + norms, AdaptiveMixing's split-K reduction + norm2, fusion + norm, FFN + norm3,
+ * cls / reg branches, refine_bbox, velocity scaling, theta_d2xy (models/racformer_transformer.py:230-236,
+ * 249-269; models/bev_self_attention.py:221-225).  embed_dims must be 256, code_size 10, num_classes <= 16.
+ *   acts[10]    HOST array of device pointers: x1 [n,256], bev_r [n,256], bev_l [n,256],
+ *               partials [num_partials][n,256] (stride partial_stride floats), query_bbox [n,10],
+ *               time_diff_safe [B,T]; outputs x3 [n,256], cls [n,num_classes], bbox_pred [n,10], bbox_xy [n,10]
+ *   weights[37] HOST array of device pointers, dense weights TRANSPOSED to [in][out] (10-wide heads padded to
+ *               16 columns), in this order: Wor,bor, Wol,bol, b_mix, (gamma,beta) of norm_radar, norm_lss, norm2,
+ *               Wf,bf,(g,b) norm_fusion, W1,b1,W2,b2,(g,b) norm3, Wc0,bc0,(g,b), Wc3,bc3,(g,b), Wc6,bc6,
+ *               Wr0,br0, Wr2,br2, Wr4,br4 */
+int rac_layer_tail_fwd(const void *const *acts, const void *const *weights, int num_partials,
+                       int64_t partial_stride, int B, int Q, int T, int num_classes, int code_size,
+                       float num_ray, float eps, void *stream);
 
 /* Row-wise  out = [relu]( LayerNorm( sum_{s<num_partials} a[s] + residual + bias ) * gamma + beta ).
  * Replaces the add / bias / split-K reduce + nn.LayerNorm (+ ReLU) launch groups of the decoder layer

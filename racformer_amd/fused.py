@@ -187,3 +187,59 @@ def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1):
                                    _lib.ptr(out), rows, dim, float(norm.eps), int(relu), _lib.stream_ptr())
     _lib.check(rc, "rac_add_ln_fwd")
     return out
+
+
+class LayerTailWeights:
+    """Transposed / padded copies of the decoder-layer tail weights for rac_layer_tail_fwd, built once per
+    forward (the six layers share them).  Holds the tensors alive and the ctypes pointer table."""
+
+    def __init__(self, layer):
+        def t(lin, pad_to=None):
+            w = lin.weight.detach().t().contiguous()           # [in][out]
+            b = lin.bias.detach()
+            if pad_to is not None and w.shape[1] < pad_to:
+                w = torch.cat([w, w.new_zeros(w.shape[0], pad_to - w.shape[1])], dim=1).contiguous()
+                b = torch.cat([b, b.new_zeros(pad_to - b.shape[0])]).contiguous()
+            return [w, b.contiguous()]
+
+        def ln(norm):
+            return [norm.weight.detach().contiguous(), norm.bias.detach().contiguous()]
+
+        rb, lb, cb, rg = layer.sampling_radar_bev, layer.sampling_lss_bev, layer.cls_branch, layer.reg_branch
+        self.tensors = (t(rb.attention.output_proj) + t(lb.attention.output_proj)
+                        + [layer.mixing.out_proj.bias.detach().contiguous()]
+                        + ln(layer.norm_radar_bev) + ln(layer.norm_lss_bev) + ln(layer.norm2)
+                        + t(layer.fusion) + ln(layer.norm_fusion)
+                        + t(layer.ffn.layers[0][0]) + t(layer.ffn.layers[1]) + ln(layer.norm3)
+                        + t(cb[0]) + ln(cb[1]) + t(cb[3]) + ln(cb[4]) + t(cb[6], 16)
+                        + t(rg[0]) + t(rg[2]) + t(rg[4], 16))
+        assert len(self.tensors) == 37
+        self.table = (ctypes.c_void_p * 37)(*[x.data_ptr() for x in self.tensors])
+        self.num_classes = cb[6].weight.shape[0]
+        self.code_size = rg[4].weight.shape[0]
+        self.eps = float(layer.norm3.eps)
+
+
+def layer_tail_fused(tw, x1, bev_r, bev_l, partials, query_bbox, time_diff_safe, num_ray):
+    """-> (x3 [B,Q,256], cls [B,Q,num_classes], bbox_pred [B,Q,10], bbox_xy [B,Q,10])."""
+    x1, bev_r, bev_l, partials, query_bbox = (v.contiguous() for v in (x1, bev_r, bev_l, partials, query_bbox))
+    _lib.require_gpu(x1, bev_r, bev_l, partials, query_bbox, time_diff_safe, what="layer_tail_fused")
+    B, Q, E = x1.shape
+    if E != 256:
+        raise RuntimeError("layer_tail_fused: embed_dims must be 256")
+    S = partials.shape[0]
+    x3 = torch.empty_like(x1)
+    cls = torch.empty(B, Q, tw.num_classes, device=x1.device, dtype=torch.float32)
+    pred, xy = torch.empty(B, Q, 10, device=x1.device), torch.empty(B, Q, 10, device=x1.device)
+    acts = (ctypes.c_void_p * 10)(x1.data_ptr(), bev_r.data_ptr(), bev_l.data_ptr(), partials.data_ptr(),
+                                  query_bbox.data_ptr(), time_diff_safe.data_ptr(), x3.data_ptr(), cls.data_ptr(),
+                                  pred.data_ptr(), xy.data_ptr())
+    ev = _lib.timer.record("layer_tail_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_layer_tail_fwd(acts, tw.table, S, B * Q * E, B, Q, time_diff_safe.shape[1], tw.num_classes,
+                                       tw.code_size, float(num_ray), tw.eps, _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_layer_tail_fwd")
+    return x3, cls, pred, xy

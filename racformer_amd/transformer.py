@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import add_ln, bev_sampling_fused, box_prep, mixing_fused, refine_fused, sampling4d_fused, sasa_fused
+from .fused import LayerTailWeights, add_ln, bev_sampling_fused, layer_tail_fused, box_prep, mixing_fused, refine_fused, sampling4d_fused, sasa_fused
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -575,6 +575,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         self.d_region_list = d_region_list
         self.num_ray = num_ray
         self.fused = True  # False: the reference's op decomposition (torch keypoints + msmv / MSDA operators)
+        self.tail_kernel = True  # one-launch layer tail (rac_layer_tail_fwd); False: GEMMs + add_ln + refine kernels
 
     @torch.no_grad()
     def init_weights(self):
@@ -610,7 +611,9 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         w, b, widths = self._wide_linears()
         return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
                     wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=self.mixing.split_out_proj(),
-                    sasa_w=self.self_attn.wide_in_proj())
+                    sasa_w=self.self_attn.wide_in_proj(),
+                    **({"tail": LayerTailWeights(self)} if self.fused and self.tail_kernel and radar_value.is_cuda
+                       and self.embed_dims == 256 and self.code_size == 10 and self.num_classes <= 16 else {}))
 
     def forward_fused(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None):
         """The layer as a chain of library GEMMs and hand-written HIP kernels only: every LayerNorm is fused
@@ -635,18 +638,26 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
         r_off, r_ray, r_sc, r_qu = lin[3:7]
         l_off, l_ray, l_sc, l_qu = lin[7:11]
-        r_proj = rb.attention.output_proj(bev_sampling_fused(
+        bev_r = bev_sampling_fused(
             prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff, rb.num_frames,
-            rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region, box_table=table))
-        l_proj = lb.attention.output_proj(bev_sampling_fused(
+            rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region, box_table=table)
+        bev_l = bev_sampling_fused(
             prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff, lb.num_frames,
-            lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region, box_table=table))
-        query_radar_feat = add_ln(r_proj, self.norm_radar_bev, residual=x1)
-        query_lss_feat = add_ln(l_proj, self.norm_lss_bev, residual=x1)
+            lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region, box_table=table)
         sampled_feat = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=lin[0:3],
                                      box_table=table)
-        # adaptive mixing: split-K partial sums + bias + residual are folded into norm2
+        # adaptive mixing: generator GEMM -> MFMA kernel -> split-K partial products of out_proj
         partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"])
+        if stages is None and self.tail_kernel and "tail" in prepared:
+            # everything that remains of the layer in one launch (rac_layer_tail_fwd)
+            x3, cls_score, bbox_pred, bbox_xy = layer_tail_fused(prepared["tail"], x1, bev_r, bev_l, partials, qb,
+                                                                 meta["time_diff_safe"], self.num_ray)
+            self.last_bbox_xy = bbox_xy
+            return x3, cls_score, bbox_pred
+        r_proj = rb.attention.output_proj(bev_r)
+        l_proj = lb.attention.output_proj(bev_l)
+        query_radar_feat = add_ln(r_proj, self.norm_radar_bev, residual=x1)
+        query_lss_feat = add_ln(l_proj, self.norm_lss_bev, residual=x1)
         x2 = add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0])
         f = add_ln(self.fusion(torch.cat((x2, query_radar_feat, query_lss_feat), dim=-1)), self.norm_fusion)
         ffn_lin = self.ffn.layers[1](F.relu(self.ffn.layers[0][0](f)))

@@ -138,3 +138,29 @@ def test_refine_and_add_ln_kernels():
                      num_partials=S)
         assert (got.cpu() - want.detach()).abs().max().item() < 2e-5, (dim, S)
         ln.cpu()
+
+
+@pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])
+def test_layer_tail_kernel_matches_op_chain(cfg):
+    """rac_layer_tail_fwd (one launch) vs the same layer run as GEMMs + add_ln + refine kernels, and vs the
+    reference op decomposition: whole-decoder outputs on identical inputs."""
+    outs = {}
+    for mode in ("tail", "chain", "unfused"):
+        tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+        syn.fill_params(tr, 52)
+        layer = tr.decoder.decoder_layer
+        layer.fused = mode != "unfused"
+        layer.tail_kernel = mode == "tail"
+        tr = tr.to(DEV)
+        qb, qf = syn.make_queries(cfg, 51)
+        with torch.no_grad():
+            outs[mode] = tr(qb.to(DEV), qf.to(DEV), [f.to(DEV) for f in syn.make_pyramid(cfg, 51)],
+                            syn.make_bev(cfg, 51, 0).to(DEV), syn.make_bev(cfg, 51, 1).to(DEV), None,
+                            syn.make_img_metas(cfg))
+    torch.cuda.synchronize()
+    from parity import decoder_parity
+    decoder_parity(outs["tail"][0], outs["tail"][1], outs["chain"][0].cpu(), outs["chain"][1].cpu(), what="tail vs chain")
+    decoder_parity(outs["tail"][0], outs["tail"][1], outs["unfused"][0].cpu(), outs["unfused"][1].cpu(), what="tail vs unfused")
+    # layer 0 has no upstream divergence: tight check of the kernel itself
+    assert (outs["tail"][0][0] - outs["chain"][0][0]).abs().max().item() < 1e-4
+    assert (outs["tail"][1][0] - outs["chain"][1][0]).abs().max().item() < 1e-4

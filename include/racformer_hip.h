@@ -145,8 +145,8 @@ int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, fl
  *   acts[10]    HOST array of device pointers: x1 [n,256], bev_r [n,256], bev_l [n,256],
  *               partials [num_partials][n,256] (stride partial_stride floats), query_bbox [n,10],
  *               time_diff_safe [B,T]; outputs x3 [n,256], cls [n,num_classes], bbox_pred [n,10], bbox_xy [n,10]
- *   weights[37] HOST array of device pointers, dense weights TRANSPOSED to [in][out] (10-wide heads padded to
- *               16 columns), in this order: Wor,bor, Wol,bol, b_mix, (gamma,beta) of norm_radar, norm_lss, norm2,
+ *   weights[37] HOST array of device pointers, dense weights in nn.Linear's native [out][in] layout (the 10-wide
+ *               heads zero-padded to 16 rows / 16 bias entries), in this order: Wor,bor, Wol,bol, b_mix, (gamma,beta) of norm_radar, norm_lss, norm2,
  *               Wf,bf,(g,b) norm_fusion, W1,b1,W2,b2,(g,b) norm3, Wc0,bc0,(g,b), Wc3,bc3,(g,b), Wc6,bc6,
  *               Wr0,br0, Wr2,br2, Wr4,br4 */
 int rac_layer_tail_fwd(const void *const *acts, const void *const *weights, int num_partials,

@@ -25,7 +25,7 @@ struct TailArgs {
     // activations
     const float *x1, *bev_r, *bev_l, *partials, *qbox, *td_safe;
     float *x3, *cls, *pred, *xy;
-    // transposed weights [in][out] (out padded to 16) and biases / LayerNorm affine pairs
+    // weights in torch's native [out][in] layout (10-wide heads zero-padded to 16 rows), biases, LayerNorm affine pairs
     const float *Wor, *bor, *Wol, *bol, *b_mix;
     const float *g_r, *be_r, *g_l, *be_l, *g_2, *be_2;
     const float *Wf, *bf, *g_f, *be_f;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void layer_tail_kernel(const TailArgs a)
     // ---- f = LN_f(fusion(cat)) ---------------------------------------------------------------------
     {
         rm_f4 acc[4] = {};
-        rm_gemm<3 * LT_E, 4>(sCat, LT_LDCAT, a.Wf, LT_E, wave, lane, acc);
+        rm_gemm<3 * LT_E, 4>(sCat, LT_LDCAT, a.Wf, 3 * LT_E, wave, lane, acc);
         rm_store<4>(acc, a.bf, nullptr, 0, sF, LT_LD, 0, wave, lane);
     }
     __syncthreads();
@@ -109,15 +109,16 @@ __global__ __launch_bounds__(256) void layer_tail_kernel(const TailArgs a)
 
     // ---- FFN: x3 = LN3(f + W2 relu(W1 f + b1) + b2) -------------------------------------------------
     float *sH = sCat;  // [16][516] hidden (the concat tile is dead)
-    {
-        rm_f4 acc[8] = {};
-        rm_gemm<LT_E, 8>(sF, LT_LD, a.W1, 2 * LT_E, wave, lane, acc);
-        rm_store<8>(acc, a.b1, nullptr, 0, sH, RM_LD(2 * LT_E), 1, wave, lane);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {   // 512 outputs as two 256-wide passes
+        rm_f4 acc[4] = {};
+        rm_gemm<LT_E, 4>(sF, LT_LD, a.W1 + (size_t)half * LT_E * LT_E, LT_E, wave, lane, acc);
+        rm_store<4>(acc, a.b1 + half * LT_E, nullptr, 0, sH + half * LT_E, RM_LD(2 * LT_E), 1, wave, lane);
     }
     __syncthreads();
     {
         rm_f4 acc[4] = {};
-        rm_gemm<2 * LT_E, 4>(sH, RM_LD(2 * LT_E), a.W2, LT_E, wave, lane, acc);
+        rm_gemm<2 * LT_E, 4>(sH, RM_LD(2 * LT_E), a.W2, 2 * LT_E, wave, lane, acc);
         rm_store<4>(acc, a.b2, sF, LT_LD, sX, LT_LD, 0, wave, lane);
     }
     __syncthreads();
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void layer_tail_kernel(const TailArgs a)
     __syncthreads();
     if (wave == 0) {
         rm_f4 acc[1] = {};
-        rm_gemm<LT_E, 1>(sA, LT_LD, a.Wc6, 16, 0, lane, acc);
+        rm_gemm<LT_E, 1>(sA, LT_LD, a.Wc6, LT_E, 0, lane, acc);
         rm_store<1>(acc, a.bc6, nullptr, 0, sD, 20, 0, 0, lane);
     }
     // ---- reg branch (first layer overlaps with the cls head on waves 1-3 of the next barrier) ---------
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void layer_tail_kernel(const TailArgs a)
     __syncthreads();
     if (wave == 0) {
         rm_f4 acc[1] = {};
-        rm_gemm<LT_E, 1>(sA, LT_LD, a.Wr4, 16, 0, lane, acc);
+        rm_gemm<LT_E, 1>(sA, LT_LD, a.Wr4, LT_E, 0, lane, acc);
         rm_store<1>(acc, a.br4, nullptr, 0, sD, 20, 0, 0, lane);
     }
     __syncthreads();

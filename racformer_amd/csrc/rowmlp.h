@@ -4,11 +4,10 @@
 // (256..768 -> 10..2189 features) on it without leaving the CU: activations live in LDS, weights
 // stream from L2 exactly once per workgroup, each dense layer is a sequence of
 // v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate = an fmaf chain, i.e. fp32 GEMM accuracy).
-//   A operand  = activations  sIn[row = lane&15][k = 4*step + (lane>>4)]        (LDS, ld = K+4)
-//   B operand  = weights^T    Wt[k = 4*step + (lane>>4)][col = 16*tile + (lane&15)]  (global, [K][ldW])
+//   A operand  = activations  sIn[row = lane&15][k]        (LDS, ld = K+4)
+//   B operand  = weights      W[col = 16*tile + (lane&15)][k]   (global, torch's native [out][in] layout)
 //   C/D        = out[row = 4*(lane>>4) + r][col = 16*tile + (lane&15)],  r = 0..3
-// Wave w computes column tiles w, w+4, w+8, ...  Weights are stored transposed ([in][out], out padded
-// to a multiple of 16) so that a B-operand load is four 64-byte segments.
+// Wave w computes column tiles w, w+4, w+8, ...  (out features padded to a multiple of 16 rows of W).
 #pragma once
 #include "rac_common.h"
 
@@ -17,24 +16,44 @@ typedef float rm_f4 __attribute__((ext_vector_type(4)));
 #define RM_ROWS 16
 #define RM_LD(K) ((K) + 4) /* LDS row stride of a [16][K] activation tile: 16-byte aligned, low-conflict */
 
-// acc[j] += sIn[16 x K] @ Wt[K x (tiles of this wave)];  TPW = tiles per wave (compile time)
+// acc[j] += sIn[16 x K] @ W^T for the column tiles of this wave;  TPW = tiles per wave (compile time).
+// W is in torch's native Linear layout [out][in] (ldW = in features).  The k index of an MFMA step is
+// only a summation index, so it is assigned such that one 16-byte load feeds four steps: in the group of
+// steps 4u..4u+3, lane (li, lk) supplies k = 16u + 4*lk + i for step i -- i.e. the float4
+// W[col][16u+4lk .. +3] (global) and sIn[row][16u+4lk .. +3] (LDS), A and B permuted identically.
 template <int K, int TPW>
-__device__ __forceinline__ void rm_gemm(const float *__restrict__ sIn, int ldIn, const float *__restrict__ Wt, int ldW,
+__device__ __forceinline__ void rm_gemm(const float *__restrict__ sIn, int ldIn, const float *__restrict__ W, int ldW,
                                         int wave, int lane, rm_f4 (&acc)[TPW])
 {
     const int li = lane & 15, lk = lane >> 4;
-    const float *ap = sIn + li * ldIn + lk;
-    const float *bp = Wt + (size_t)lk * ldW + 16 * wave + li;
+    const float *ap = sIn + li * ldIn + 4 * lk;
+    const float *bp = W + (size_t)(16 * wave + li) * ldW + 4 * lk;
+    constexpr int U = K / 16;
+    // Every workgroup streams the same weights: start each one at a different k-block so that the 57
+    // tiles do not hit the same L2 lines in lock step (the k order is only a summation order).
+    const int u0 = (blockIdx.x * 5) % U;
 #pragma unroll 4
-    for (int s = 0; s < K / 4; ++s) {
-        const float a = ap[4 * s];
-        float b[TPW];
+    for (int i = 0; i < U; ++i) {
+        int u = u0 + i;
+        u = u >= U ? u - U : u;
+        const rac_f4 a4 = *reinterpret_cast<const rac_f4 *>(ap + 16 * u);
+        rac_f4 b4[TPW];
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
-            b[j] = bp[(size_t)(4 * s) * ldW + 64 * j];
+            b4[j] = rac_ld4(bp + (size_t)(64 * j) * ldW + 16 * u);
+        // k-major order: consecutive MFMAs hit different accumulators (40-cycle dependent latency)
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[j].w, acc[j], 0, 0, 0);
     }
 }
 

@@ -190,17 +190,18 @@ def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1):
 
 
 class LayerTailWeights:
-    """Transposed / padded copies of the decoder-layer tail weights for rac_layer_tail_fwd, built once per
-    forward (the six layers share them).  Holds the tensors alive and the ctypes pointer table."""
+    """Pointer table of the decoder-layer tail weights for rac_layer_tail_fwd (native nn.Linear layout; only
+    the two 10-wide heads are copied, zero-padded to 16 rows), built once per forward (the six layers share
+    the weights).  Holds the tensors alive."""
 
     def __init__(self, layer):
         def t(lin, pad_to=None):
-            w = lin.weight.detach().t().contiguous()           # [in][out]
-            b = lin.bias.detach()
-            if pad_to is not None and w.shape[1] < pad_to:
-                w = torch.cat([w, w.new_zeros(w.shape[0], pad_to - w.shape[1])], dim=1).contiguous()
+            w = lin.weight.detach().contiguous()               # native [out][in]
+            b = lin.bias.detach().contiguous()
+            if pad_to is not None and w.shape[0] < pad_to:
+                w = torch.cat([w, w.new_zeros(pad_to - w.shape[0], w.shape[1])], dim=0).contiguous()
                 b = torch.cat([b, b.new_zeros(pad_to - b.shape[0])]).contiguous()
-            return [w, b.contiguous()]
+            return [w, b]
 
         def ln(norm):
             return [norm.weight.detach().contiguous(), norm.bias.detach().contiguous()]

@@ -575,7 +575,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         self.d_region_list = d_region_list
         self.num_ray = num_ray
         self.fused = True  # False: the reference's op decomposition (torch keypoints + msmv / MSDA operators)
-        self.tail_kernel = True  # one-launch layer tail (rac_layer_tail_fwd); False: GEMMs + add_ln + refine kernels
+        # One-launch layer tail (rac_layer_tail_fwd).  Off by default: measured 168 us per layer against ~110 us
+        # for the chain of library GEMMs + add_ln + refine kernels it replaces -- a 16-row tile has to pull the
+        # tail's 3.5 MB of weights through ONE CU's L2 port (~70 GB/s), which bounds it near 50 us + 44 us of MFMA.
+        self.tail_kernel = False
 
     @torch.no_grad()
     def init_weights(self):

@@ -493,12 +493,15 @@ class AdaptiveMixing(nn.Module):
         B, Q, G, P, C = x.shape
         return x.is_cuda and C == 64 and self.eff_out_dim == 64 and self.out_points == 128 and P <= 96
 
-    def out_proj_partials(self, x, query, out_proj_split):
+    def out_proj_partials(self, x, query, out_proj_split, params=None):
         """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
         out_proj.  Returns the S partial products [S, B*Q, query_dim]; their sum + out_proj.bias + query
-        is inner_forward's result (the caller folds that sum into its LayerNorm kernel)."""
+        is inner_forward's result (the caller folds that sum into its LayerNorm kernel).  ``params``:
+        the generator output if the caller already produced it (on a side stream)."""
         B, Q, G, P, C = x.shape
-        out = mixing_fused(x.contiguous(), self.parameter_generator(query), P, G, self.out_points)
+        if params is None:
+            params = self.parameter_generator(query)
+        out = mixing_fused(x.contiguous(), params, P, G, self.out_points)
         S_, N, k = out_proj_split.shape
         return torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
 
@@ -579,6 +582,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # for the chain of library GEMMs + add_ln + refine kernels it replaces -- a 16-row tile has to pull the
         # tail's 3.5 MB of weights through ONE CU's L2 port (~70 GB/s), which bounds it near 50 us + 44 us of MFMA.
         self.tail_kernel = False
+        # Run the mixing parameter generator (MFMA-bound) on a second stream beside the sampling kernels
+        # (memory-bound).  Measured: no gain on MI355X (92.9 vs 92.7 samples/s) -- the GEMM's workgroups occupy every
+        # CU, the kernels do not co-schedule -- so it stays off.
+        self.overlap = False
 
     @torch.no_grad()
     def init_weights(self):
@@ -595,6 +602,11 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         dz_new = torch.sigmoid(bbox_delta[..., 1:3] + inverse_sigmoid(bbox_proposal[..., 1:3]))
         theta = bbox_proposal[..., 0:1] + (torch.sigmoid(bbox_delta[..., 0:1]) * 2 - 1) / self.num_ray
         return torch.cat([theta, dz_new, bbox_delta[..., 3:]], dim=-1)
+
+    def _side_stream(self, device):
+        if getattr(self, "_side", None) is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def _wide_linears(self):
         """The eleven Linear(256 -> .) layers that all read the post-norm1 query features, as one
@@ -615,6 +627,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
                     wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=self.mixing.split_out_proj(),
                     sasa_w=self.self_attn.wide_in_proj(),
+                    **({"side_stream": self._side_stream(radar_value.device)} if radar_value.is_cuda else {}),
                     **({"tail": LayerTailWeights(self)} if self.fused and self.tail_kernel and radar_value.is_cuda
                        and self.embed_dims == 256 and self.code_size == 10 and self.num_classes <= 16 else {}))
 
@@ -635,6 +648,20 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         lin = F.linear(x, prepared["sasa_w"][0], prepared["sasa_w"][1])
         attn = p.out_proj(sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], qb, self.self_attn.num_heads, self.pc_range))
         x1 = add_ln(attn, self.norm1, residual=x)
+        # The 30-GFLOP parameter generator of AdaptiveMixing needs only x1.  It is MFMA-bound while the three
+        # sampling kernels are memory / L2-bound, so it runs on a second HIP stream beside them.
+        params = None
+        side = prepared.get("side_stream") if self.overlap else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                params = self.mixing.parameter_generator(x1)
+                done = torch.cuda.Event()
+                done.record(side)
+            params.record_stream(main)
         # the three sampling modules: one wide GEMM, one box table, three fused kernels
         lin = F.linear(x1, prepared["wide_w"], prepared["wide_b"]).split(prepared["wide_widths"], dim=-1)
         table = box_prep(qb, self.pc_range)
@@ -650,7 +677,9 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         sampled_feat = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=lin[0:3],
                                      box_table=table)
         # adaptive mixing: generator GEMM -> MFMA kernel -> split-K partial products of out_proj
-        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"])
+        if side is not None:
+            torch.cuda.current_stream().wait_event(done)
+        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], params)
         if stages is None and self.tail_kernel and "tail" in prepared:
             # everything that remains of the layer in one launch (rac_layer_tail_fwd)
             x3, cls_score, bbox_pred, bbox_xy = layer_tail_fused(prepared["tail"], x1, bev_r, bev_l, partials, qb,

@@ -21,6 +21,7 @@
  *   rac_box_prep_fwd  <- decode_bbox(theta_d2xy_coods(.)) models/bbox/utils.py:66-90 (shared prologue)
  *   rac_sampling4d_fwd<- RaCFormerSampling.inner_forward + sampling_4d + msmv op, fused
  *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
+ *   rac_bev_pool_v2_fwd/_bwd <- bev_pool_v2_ext (models/csrc/bev_pool_v2/src/bev_pool.cpp:40-111), row f2
  *   rac_layer_tail_fwd<- decoder-layer tail (projections, norms, fusion, FFN, branches, refine), one launch
  *                        models/racformer_transformer.py:249-269
  *   rac_add_ln_fwd    <- residual add + nn.LayerNorm (+ReLU) groups, models/racformer_transformer.py:170-258
@@ -178,6 +179,21 @@ int rac_refine_fwd(const float *proposal, const float *delta, const float *time_
  *   out    : device f32 [num_query, groups, 128, 64] */
 int rac_mixing_fwd(const float *x, const float *params, float *out, int ld_params, int num_query, int groups,
                    int in_points, int channels, int out_points, float eps, void *stream);
+
+/* BEVPoolv2 (Lift-Splat-Shoot voxel pooling) -- SURVEY.md section 8 "next" row f2.  Replaces
+ * bev_pool_v2_forward / bev_pool_v2_backward of models/csrc/bev_pool_v2/src/bev_pool.cpp:40-111
+ * (kernels bev_pool_cuda.cu:21-136); argument order follows those entry points.
+ *   depth [b,n,d,h,w] f32, feat [b,n,h,w,c] f32, out [b,z,y,x,c] f32 (pre-zeroed by the caller, as in
+ *   bev_pool.py:29), ranks_* int32 [n_points], interval_* int32 [n_intervals]; all device pointers.
+ * Backward expects the intervals regrouped by ranks_feat (bev_pool.py:50-63) and depth_grad / feat_grad
+ * pre-zeroed.  Deterministic: one writer per output element, no atomics. */
+int rac_bev_pool_v2_fwd(const float *depth, const float *feat, float *out, const int32_t *ranks_depth,
+                        const int32_t *ranks_feat, const int32_t *ranks_bev, const int32_t *interval_lengths,
+                        const int32_t *interval_starts, int c, int n_intervals, void *stream);
+int rac_bev_pool_v2_bwd(const float *out_grad, float *depth_grad, float *feat_grad, const float *depth,
+                        const float *feat, const int32_t *ranks_depth, const int32_t *ranks_feat,
+                        const int32_t *ranks_bev, const int32_t *interval_lengths, const int32_t *interval_starts,
+                        int c, int n_intervals, void *stream);
 
 #ifdef __cplusplus
 }

@@ -606,3 +606,19 @@ def nms_free_decode(cls_scores, bbox_preds, max_num=300, num_classes=10, score_t
     boxes = boxes.clone()
     boxes[:, 2] = boxes[:, 2] - boxes[:, 5] * 0.5
     return dict(bboxes=boxes, scores=scores, labels=labels, query_index=bidx[mask])
+
+
+# =============================================================================== bev_pool_v2 (row f2)
+def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths):
+    """BEVPoolv2 forward restated from models/csrc/bev_pool_v2/src/bev_pool_cuda.cu:21-48 with plain torch
+    indexing (differentiable, so autograd of this function is the oracle for the backward kernel too):
+    out[ranks_bev[start_s]] = sum_{i in interval s} depth[ranks_depth[i]] * feat[ranks_feat[i]].
+    Returns [B, C, Z, Y, X] like bev_pool.py:87-92.  PINNED by the reference's inline known-answer vectors
+    (tests/golden/bev_pool_known_answer.json)."""
+    c = feat.shape[-1]
+    contrib = feat.reshape(-1, c)[ranks_feat.long()] * depth.reshape(-1)[ranks_depth.long()][:, None]
+    seg = torch.repeat_interleave(torch.arange(interval_starts.shape[0]), interval_lengths.long())
+    sums = torch.zeros(interval_starts.shape[0], c, dtype=contrib.dtype).index_add(0, seg, contrib)
+    out = torch.zeros(int(np.prod(bev_feat_shape[:-1])), c, dtype=contrib.dtype)
+    out = out.index_copy(0, ranks_bev.long()[interval_starts.long()], sums)
+    return out.reshape(*bev_feat_shape).permute(0, 4, 1, 2, 3).contiguous()

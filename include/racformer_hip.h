@@ -21,6 +21,7 @@
  *   rac_box_prep_fwd  <- decode_bbox(theta_d2xy_coods(.)) models/bbox/utils.py:66-90 (shared prologue)
  *   rac_sampling4d_fwd<- RaCFormerSampling.inner_forward + sampling_4d + msmv op, fused
  *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
+ *   rac_msmv_bwd / rac_msda_bwd <- the two operators' backward entry points (row f4)
  *   rac_bev_pool_v2_fwd/_bwd <- bev_pool_v2_ext (models/csrc/bev_pool_v2/src/bev_pool.cpp:40-111), row f2
  *   rac_layer_tail_fwd<- decoder-layer tail (projections, norms, fusion, FFN, branches, refine), one launch
  *                        models/racformer_transformer.py:249-269
@@ -179,6 +180,22 @@ int rac_refine_fwd(const float *proposal, const float *delta, const float *time_
  *   out    : device f32 [num_query, groups, 128, 64] */
 int rac_mixing_fwd(const float *x, const float *params, float *out, int ld_params, int num_query, int groups,
                    int in_points, int channels, int out_points, float eps, void *stream);
+
+/* Backward of the two gather operators (SURVEY.md section 8 "next" row f4; fp32 features only).
+ * rac_msmv_bwd  <- _ms_deform_attn_cuda_{c45,c2345,c23456}_backward, models/csrc/msmv_sampling/msmv_sampling.cpp:302-497
+ *                  (kernels msmv_sampling_backward.cu:108-440): grad_out [S,Q,C,P]; grad_feats[l] like feats[l] and
+ *                  ZERO-FILLED by the caller; grad_loc [S,Q,P,3] (view component = 0), grad_w [S,Q,P,L] overwritten.
+ * rac_msda_bwd  <- mmcv `_ext.ms_deform_attn_backward`, call site models/multi_scale_deformable_attn_function.py:148-158:
+ *                  grad_out [bs,Q,heads*dim]; grad_value like value, ZERO-FILLED by the caller; grad_loc / grad_attn
+ *                  like loc / attn, overwritten.
+ * grad_loc / grad_w / grad_attn have one writer per element (deterministic); the feature / value scatter uses float
+ * atomics, so those two gradients can differ in the last bits from run to run (as in the reference). */
+int rac_msmv_bwd(const float *grad_out, const void *const *feats, const int32_t *hw, int L, const float *loc,
+                 const float *w, void *const *grad_feats, float *grad_loc, float *grad_w, int S, int N, int Q,
+                 int P, int C, void *stream);
+int rac_msda_bwd(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *starts,
+                 const float *loc, const float *attn, float *grad_value, float *grad_loc, float *grad_attn,
+                 int bs, int keys, int heads, int dim, int Q, int L, int P, void *stream);
 
 /* BEVPoolv2 (Lift-Splat-Shoot voxel pooling) -- SURVEY.md section 8 "next" row f2.  Replaces
  * bev_pool_v2_forward / bev_pool_v2_backward of models/csrc/bev_pool_v2/src/bev_pool.cpp:40-111

@@ -1,7 +1,7 @@
 """Drop-in for ``models/multi_scale_deformable_attn_function.py`` of the reference:
 ``MultiScaleDeformableAttnFunction_fp32`` / ``_fp16`` with the same ``apply`` signature
 (:93-128), on top of ``rac_msda_fwd`` (hand-written HIP, racformer_amd/csrc/msda_fwd.hip).
-Forward only this round."""
+Forward and backward (fp32)."""
 import ctypes
 
 import torch
@@ -58,12 +58,28 @@ class MultiScaleDeformableAttnFunction_fp32(torch.autograd.Function):
         step = min(bs, int(im2col_step))
         if step > 0 and bs % step != 0:
             raise RuntimeError(f"batch({bs}) must divide im2col_step({step})")  # mmcv's check
-        return msda_forward(value.float().contiguous(), value_spatial_shapes, value_level_start_index,
-                            sampling_locations.float().contiguous(), attention_weights.float().contiguous())
+        value, loc, attn = (value.float().contiguous(), sampling_locations.float().contiguous(),
+                            attention_weights.float().contiguous())
+        ctx.levels = (_host_i64(value_spatial_shapes), _host_i64(value_level_start_index))
+        ctx.save_for_backward(value, loc, attn)
+        return msda_forward(value, value_spatial_shapes, value_level_start_index, loc, attn)
 
     @staticmethod
     def backward(ctx, grad_output):
-        raise NotImplementedError("racformer_amd: MSDA backward is not built yet (inference path only)")
+        """-> (grad_value, None, None, grad_sampling_loc, grad_attn_weight, None), as
+        multi_scale_deformable_attn_function.py:130-162."""
+        value, loc, attn = ctx.saved_tensors
+        (shapes, _), (starts, _) = ctx.levels
+        bs, keys, heads, dim = value.shape
+        _, Q, _, L, P, _ = loc.shape
+        grad_output = grad_output.contiguous().float()
+        grad_value = torch.zeros_like(value)
+        grad_loc, grad_attn = torch.empty_like(loc), torch.empty_like(attn)
+        rc = _lib.lib().rac_msda_bwd(_lib.ptr(grad_output), _lib.ptr(value), shapes, starts, _lib.ptr(loc), _lib.ptr(attn),
+                                     _lib.ptr(grad_value), _lib.ptr(grad_loc), _lib.ptr(grad_attn), bs, keys, heads, dim,
+                                     Q, L, P, _lib.stream_ptr())
+        _lib.check(rc, "rac_msda_bwd")
+        return grad_value, None, None, grad_loc, grad_attn, None
 
 
 class MultiScaleDeformableAttnFunction_fp16(MultiScaleDeformableAttnFunction_fp32):

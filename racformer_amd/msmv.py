@@ -5,7 +5,7 @@
 Same names, argument meaning and error behaviour as the reference (wrapper.py:78-153,
 msmv_sampling.cpp:132-184): features channel-last ``[B', N, H, W, C]``, contiguous device tensors,
 ``RuntimeError`` on non-contiguous / non-device inputs and on ``P > 128``; the result is a new
-``[B', Q, C, P]`` float32 tensor.  Forward only this round (backward raises).
+``[B', Q, C, P]`` float32 tensor.  ``backward`` runs rac_msmv_bwd (fp32 features).
 """
 import ctypes
 
@@ -60,15 +60,42 @@ def msmv_forward(mlvl_feats, sampling_locations, scale_weights, out_layout=_lib.
     return out
 
 
+def msmv_backward(grad_output, mlvl_feats, sampling_locations, scale_weights):
+    """rac_msmv_bwd: -> (grad_feats (list), grad_sampling_locations, grad_scale_weights), the tuple the
+    reference's ``_ms_deform_attn_cuda_*_backward`` returns (msmv_sampling.cpp:302-497).  fp32 only."""
+    feats = list(mlvl_feats)
+    L = len(feats)
+    grad_output = grad_output.contiguous()
+    _lib.require_gpu(grad_output, *feats, sampling_locations, scale_weights, what="msmv_sampling backward")
+    if any(f.dtype != torch.float32 for f in feats):
+        raise RuntimeError("msmv_sampling backward: float32 features only")
+    S, N, _, _, C = feats[0].shape
+    _, Q, P, _ = sampling_locations.shape
+    grad_feats = [torch.zeros_like(f) for f in feats]
+    grad_loc = torch.empty_like(sampling_locations)
+    grad_w = torch.empty_like(scale_weights)
+    ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    gptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in grad_feats])
+    hw = (ctypes.c_int32 * (2 * L))(*[int(x) for f in feats for x in f.shape[2:4]])
+    rc = _lib.lib().rac_msmv_bwd(_lib.ptr(grad_output), ptrs, hw, L, _lib.ptr(sampling_locations),
+                                 _lib.ptr(scale_weights), gptrs, _lib.ptr(grad_loc), _lib.ptr(grad_w), S, N, Q, P, C,
+                                 _lib.stream_ptr())
+    _lib.check(rc, "rac_msmv_bwd")
+    return grad_feats, grad_loc, grad_w
+
+
 class _MSMVBase(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *args):
         *feats, sampling_locations, scale_weights = args
+        ctx.save_for_backward(*feats, sampling_locations, scale_weights)
         return msmv_forward(feats, sampling_locations, scale_weights)
 
     @staticmethod
     def backward(ctx, grad_output):
-        raise NotImplementedError("racformer_amd: msmv backward is not built yet (inference path only)")
+        *feats, sampling_locations, scale_weights = ctx.saved_tensors
+        grad_feats, grad_loc, grad_w = msmv_backward(grad_output, feats, sampling_locations, scale_weights)
+        return (*grad_feats, grad_loc, grad_w)
 
 
 class MSMVSamplingC2345(_MSMVBase):

@@ -16,6 +16,7 @@ is written out.  What each file pins:
   sampling4d_small.npz sampling_4d (sparsebev_sampling.py:28-134) incl. slot-order quirk Q1
   msda_small.npz       multi_scale_deformable_attn_pytorch (mmcv 1.6.0 semantics, stubbed on
                        F.grid_sample in ref_loader.py; the compiled mmcv kernel is not in the tree)
+  backward_small.npz   gradients of msmv_sampling / multi_scale_deformable_attn through the CPU fallbacks
   decoder_small*.npz   full RaCFormerTransformer forward at reduced shapes + layer-0 stage outputs
   decoder_f8*.npz      full f8 shapes: cls/box outputs of all 6 layers + stage checksums
 """
@@ -149,6 +150,38 @@ def gen_msda():
          value2=value2, loc2=loc2, attn2=attn2, shapes2=np.array(hw2), out2=out2)
 
 
+def gen_backward(ref):
+    """Gradients of the two gather operators through the reference's CPU path (autograd of the
+    F.grid_sample fallbacks): pins the oracle's autograd and, through it, rac_msmv_bwd / rac_msda_bwd."""
+    wr = ref.wrapper
+    rng = np.random.default_rng(23)
+    S, N, C, Q, P = 3, 3, 8, 5, 6
+    hws = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    feats_cl = [rng.standard_normal((S, N, h, w, C), dtype=np.float32) for h, w in hws]
+    loc = rng.random((S, Q, P, 3), dtype=np.float32) * 1.1 - 0.05
+    loc[..., 2] = rng.integers(0, N, size=(S, Q, P)).astype(np.float32) / np.float32(N - 1)
+    w_ = rng.random((S, Q, P, 4), dtype=np.float32)
+    gout = rng.standard_normal((S, Q, C, P), dtype=np.float32)
+    feats_cf = [torch.from_numpy(f).permute(0, 4, 1, 2, 3).contiguous().requires_grad_() for f in feats_cl]
+    tl, tw = torch.from_numpy(loc).requires_grad_(), torch.from_numpy(w_).requires_grad_()
+    out = wr.msmv_sampling_pytorch(feats_cf, tl, tw)
+    (out * torch.from_numpy(gout)).sum().backward()
+    d = {f"feat{i}": f for i, f in enumerate(feats_cl)}
+    d.update({f"gfeat{i}": f.grad.permute(0, 2, 3, 4, 1).contiguous() for i, f in enumerate(feats_cf)})
+    # MSDA (mmcv python fallback)
+    bs, Hh, Ww, heads, D, Q2, P2 = 2, 7, 9, 2, 8, 5, 4
+    value = rng.standard_normal((bs, Hh * Ww, heads, D), dtype=np.float32)
+    mloc = rng.random((bs, Q2, heads, 1, P2, 2), dtype=np.float32) * 1.1 - 0.05
+    attn = rng.random((bs, Q2, heads, 1, P2), dtype=np.float32)
+    mg = rng.standard_normal((bs, Q2, heads * D), dtype=np.float32)
+    tv, tml, ta = (torch.from_numpy(x).requires_grad_() for x in (value, mloc, attn))
+    mo = ref_loader._msda_pytorch(tv, torch.tensor([[Hh, Ww]]), tml, ta)
+    (mo * torch.from_numpy(mg)).sum().backward()
+    save("backward_small.npz", loc=loc, w=w_, gout=gout, out=out, gloc=tl.grad, gw=tw.grad,
+         value=value, mloc=mloc, attn=attn, mgout=mg, mshape=np.array([[Hh, Ww]]), gvalue=tv.grad, gmloc=tml.grad,
+         gattn=ta.grad, **d)
+
+
 STAGES = ["position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_bev", "sampling",
           "mixing", "ffn"]
 
@@ -215,6 +248,8 @@ def main():
         gen_sampling4d(ref)
     if want("msda"):
         gen_msda()
+    if want("bwd"):
+        gen_backward(ref)
     if want("small"):
         out, dt = run_decoder(ref, syn.SMALL, seed=1, weight_seed=3, full_stages=True)
         print(f"  decoder SMALL ref forward {dt:.2f}s")

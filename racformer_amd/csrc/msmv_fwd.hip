@@ -47,7 +47,7 @@ __device__ __forceinline__ rac_f4 msmv_tap(const FT *base, int h, int w, int W, 
 }
 
 template <typename FT, int L, bool OUT_CL>
-__global__ __launch_bounds__(256, 4) void msmv_fwd_c64_kernel(const MsmvArgs a)
+__global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(const MsmvArgs a)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x;

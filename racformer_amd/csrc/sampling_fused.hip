@@ -141,7 +141,7 @@ __device__ __forceinline__ rac_f4 s4d_tap(const FT *base, int h, int w, int W, b
 }
 
 template <typename FT, int L>
-__global__ __launch_bounds__(256, S4D_WPS) void sampling4d_c64_kernel(const S4dArgs a)
+__global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_kernel(const S4dArgs a)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x;

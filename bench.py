@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--config", default="f8", choices=["f8", "f8_3cam"])
     ap.add_argument("--feature-dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blas", default="", help="torch.backends.cuda.preferred_blas_library override (experiment)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +116,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", init_method="env://", device_id=device)  # RCCL on ROCm
     _lib.lib()  # fail loudly if the HIP library is missing
+    if args.blas:
+        torch.backends.cuda.preferred_blas_library(args.blas)
 
     cfg = syn.F8 if args.config == "f8" else syn.F8_3CAM
     fdt = torch.float32 if args.feature_dtype == "f32" else torch.bfloat16

@@ -288,7 +288,7 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
     if (B == 0 || Q == 0)
         return 0;
     RAC_CHECK_ARG(box_table != nullptr, "rac_bev_sampling_fwd: box_table is null (run rac_box_prep_fwd first)");
-    RAC_CHECK_ARG(P <= 128 && heads * D <= 64, "rac_bev_sampling_fwd: P=%d / heads*D=%d exceed the workgroup's staging roles", P, heads * D);
+    RAC_CHECK_ARG(BEV_GI * P <= 128 && BEV_GI * D <= 64, "rac_bev_sampling_fwd: NP*D=%d (max %d) or D=%d (max %d) exceed the workgroup's staging roles", P, 128 / BEV_GI, D, 64 / BEV_GI);
     RAC_CHECK_ARG(value && query_bbox && offsets && ray_logits && scale_logits && queue_logits && time_diff && out &&
                       pc_range && depth_base,
                   "rac_bev_sampling_fwd: null pointer");

@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--config", default="f8", choices=["f8", "f8_3cam"])
     ap.add_argument("--feature-dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pregrouped", action="store_true",
+                    help="feed the pyramid already in the sampling layout (producer-side layout, row f2): no regroup")
     ap.add_argument("--blas", default="", help="torch.backends.cuda.preferred_blas_library override (experiment)")
     args = ap.parse_args()
 
@@ -126,6 +128,10 @@ def main():
     pyramid = [f.to(device) for f in syn.make_pyramid(cfg, seed)]
     lss, radar = syn.make_bev(cfg, seed, 0).to(device), syn.make_bev(cfg, seed, 1).to(device)
     metas = syn.make_img_metas(cfg)
+    if args.pregrouped:
+        from racformer_amd.transformer import regroup_pyramid
+        pyramid = regroup_pyramid(pyramid, cfg.num_cams, 4, fdt)
+        head.transformer.decoder.pregrouped = True
 
     def step():
         with torch.no_grad():
@@ -190,7 +196,8 @@ def main():
         "config": {"workload": f"racformer_r50_nuimg_704x256_{args.config} query-decoder hot path: regroup + 6 decoder "
                                "layers + NMS-free decode, 1 sample/GPU/step",
                    "queries": cfg.num_query, "cams": cfg.num_cams, "frames": cfg.num_frames,
-                   "levels": cfg.num_levels, "samples_per_gpu": 1, "parallelism": f"dp{world}"},
+                   "levels": cfg.num_levels, "samples_per_gpu": 1, "parallelism": f"dp{world}",
+                   "pyramid_layout": "pregrouped [B*T*G,N,H,W,C]" if args.pregrouped else "reference [B,T*N,G*C,H,W] (regroup timed)"},
         "roofline": {"bound": "hbm", "kernel": "sampling4d_c64_kernel (rac_sampling4d_fwd: keypoints + projection + view select + gather)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,

@@ -9,12 +9,12 @@
 // logits), the frame logits (bev_queue_weight), query boxes, time_diff and the hoisted value
 // stream [B*T, H*W, heads, 64]; output [B,Q,heads*64] (before output_proj).
 //
-// Workgroup = 4 items (b,q,head) (one query's 4 heads) x 4 frame subsets: a 16-lane group owns
-// (item, frames ts, ts+4, ...) with 4 channels per lane (16-byte loads).  Phase A: the T-invariant
+// Workgroup = 4 items (b,q,head) (one query's 4 heads) x 4 point subsets: a 16-lane group owns
+// (item, points ts, ts+4, ... of every frame) with 4 channels per lane (16-byte loads).  Phase A: the T-invariant
 // pieces once per item -- base points from the box table (rac_box_prep_fwd), ray-depth offsets, the
 // two softmaxes -- into LDS.  Phase B: all threads warp the base points to every frame (T*P
 // keypoints per item).  Phase C: per frame 20 points unrolled by 4 (16 taps in flight), scaled by
-// the frame weight.  Phase D: fixed-order LDS sum of the four frame subsets (deterministic).
+// the frame weight.  Phase D: fixed-order LDS sum of the four point subsets (deterministic).
 // For B>1 the reference pairs value frame i=b*T+t with the locations of (t'=i/B, b'=i%B)
 // (bev_self_attention.py:185-188 vs :162,173, quirk Q2); reproduced as written.
 #include "rac_common.h"
@@ -80,7 +80,7 @@ __device__ __forceinline__ rac_f4 bev_tap(const FT *base, long pix, int stride, 
 }
 
 #define BEV_GI 4   /* items (b,q,head) per workgroup */
-#define BEV_TS 4   /* frame subsets per item: 16-lane group (k, ts) handles frames ts, ts+4, ... */
+#define BEV_TS 4   /* point subsets per item: 16-lane group (k, ts) handles points ts, ts+4, ... of every frame */
 
 // per-(t,p) half of the keypoint chain for B==1: warp the T-invariant base point, polar jitter.
 __device__ __forceinline__ void bev_warp(const BevArgs &a, float px, float py, float vx, float vy, float td,
@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
     const int H = a.H, W = a.W, stride = a.heads * 64;
     const long keys = (long)H * W;
     if (live) {
-        for (int t = ts; t < T; t += BEV_TS) {
+        // Every group walks ALL frames in the same order and owns the points p = ts, ts+4, ... of each: the whole
+        // chip then works on (nearly) one 16.8 MB frame at a time instead of four, which the L2s / Infinity Cache
+        // hold better (measured 91 -> 76 us against splitting the frames over the groups).
+        for (int t = 0; t < T; ++t) {
             const int fi = b * T + t;
             const FT *base = (const FT *)a.value + ((size_t)fi * keys * a.heads + h) * 64 + c4 * 4;
             const float *lp = sloc + (k * TP + t * P) * 2;
@@ -213,12 +216,12 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
                 wsum_inv = 1.f / s2;
             }
             rac_f4 at = {0.f, 0.f, 0.f, 0.f};
-            for (int p0 = 0; p0 < P; p0 += 4) {
+            for (int p0 = ts; p0 < P; p0 += 4 * BEV_TS) {
                 rac_f4 v[4][4];
                 float tw[4][4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int p = p0 + u;
+                    const int p = p0 + BEV_TS * u;
                     const bool act = p < P;
                     const int pp = act ? p : P - 1;
                     const float x = lp[pp * 2], y = lp[pp * 2 + 1];
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
             acc.w += at.w * fw;
         }
     }
-    // phase D: fixed-order sum of the four frame subsets (deterministic, no atomics)
+    // phase D: fixed-order sum of the four point subsets (deterministic, no atomics)
     *reinterpret_cast<rac_f4 *>(spart + (k * BEV_TS + ts) * 64 + c4 * 4) = acc;
     __syncthreads();
     if (live && ts == 0) {

@@ -794,6 +794,9 @@ class RaCFormerTransformerDecoder(nn.Module):
             img_depth_num=img_depth_num, bev_depth_num=bev_depth_num, num_ray=num_ray, pc_range=pc_range,
             d_region_list=d_region_list, spatial_shapes=spatial_shapes)
         self.feature_dtype = torch.float32
+        # True: ``mlvl_feats`` arrive already in the sampling layout [B*T*G, N, H, W, C] (a producer that writes the
+        # grouped channel-last pyramid directly skips the 1.47 GB regroup)
+        self.pregrouped = False
 
     @torch.no_grad()
     def init_weights(self):
@@ -818,9 +821,15 @@ class RaCFormerTransformerDecoder(nn.Module):
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
                 stages_per_layer=None):
         self.stage_metas(img_metas, query_bbox.shape[0], query_bbox.device)
-        grouped = regroup_pyramid(mlvl_feats, self.num_cams, 4, self.feature_dtype)
-        for lvl, g in enumerate(grouped):
-            mlvl_feats[lvl] = g  # the reference mutates the caller's list too (:124)
+        if self.pregrouped:
+            # producer-side layout: the FPN already wrote [B*T*G, N, H, W, C]
+            for f in mlvl_feats:
+                if f.dim() != 5 or f.shape[1] != self.num_cams or not f.is_contiguous():
+                    raise RuntimeError("pregrouped pyramid levels must be contiguous [B*T*G, N, H, W, C]")
+        else:
+            grouped = regroup_pyramid(mlvl_feats, self.num_cams, 4, self.feature_dtype)
+            for lvl, g in enumerate(grouped):
+                mlvl_feats[lvl] = g  # the reference mutates the caller's list too (:124)
         prepared = self.decoder_layer.prepare(lss_bev_feats, radar_bev_feats)
         cls_scores, bbox_preds = [], []
         for i in range(self.num_layers):

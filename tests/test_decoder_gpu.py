@@ -73,3 +73,22 @@ def test_decoder_small_vs_oracle_stagewise():
             err = (gst[li][s].cpu() - ost[li][s]).abs().max().item()
             assert err < 1e-3, (li, s, err)
     decoder_parity(cls, box, ocls, obox, what="small6 vs oracle")
+
+
+def test_pregrouped_pyramid_matches_regroup_path():
+    """Producer-side layout hook (row f2): feeding [B*T*G,N,H,W,C] levels gives bit-identical outputs."""
+    from racformer_amd.transformer import regroup_pyramid
+    cfg = syn.SMALL6
+    tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+    syn.fill_params(tr, 8)
+    tr = tr.to(DEV)
+    qb, qf = syn.make_queries(cfg, 7)
+    pyr = [f.to(DEV) for f in syn.make_pyramid(cfg, 7)]
+    lss, radar = syn.make_bev(cfg, 7, 0).to(DEV), syn.make_bev(cfg, 7, 1).to(DEV)
+    with torch.no_grad():
+        a = tr(qb.to(DEV), qf.to(DEV), list(pyr), lss, radar, None, syn.make_img_metas(cfg))
+        tr.decoder.pregrouped = True
+        b = tr(qb.to(DEV), qf.to(DEV), regroup_pyramid(pyr, cfg.num_cams), lss, radar, None, syn.make_img_metas(cfg))
+        with pytest.raises(RuntimeError, match="pregrouped"):
+            tr(qb.to(DEV), qf.to(DEV), list(pyr), lss, radar, None, syn.make_img_metas(cfg))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

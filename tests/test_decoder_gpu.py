@@ -76,7 +76,8 @@ def test_decoder_small_vs_oracle_stagewise():
 
 
 def test_pregrouped_pyramid_matches_regroup_path():
-    """Producer-side layout hook (row f2): feeding [B*T*G,N,H,W,C] levels gives bit-identical outputs."""
+    """Producer-side layout hook (row f2): feeding [B*T*G,N,H,W,C] levels gives the same outputs (not asserted
+    bitwise: MIOpen may pick a different conv algorithm between the first and the second call of a process)."""
     from racformer_amd.transformer import regroup_pyramid
     cfg = syn.SMALL6
     tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
@@ -91,4 +92,4 @@ def test_pregrouped_pyramid_matches_regroup_path():
         b = tr(qb.to(DEV), qf.to(DEV), regroup_pyramid(pyr, cfg.num_cams), lss, radar, None, syn.make_img_metas(cfg))
         with pytest.raises(RuntimeError, match="pregrouped"):
             tr(qb.to(DEV), qf.to(DEV), list(pyr), lss, radar, None, syn.make_img_metas(cfg))
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert (a[0] - b[0]).abs().max().item() < 1e-4 and (a[1] - b[1]).abs().max().item() < 1e-4

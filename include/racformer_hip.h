@@ -155,13 +155,19 @@ int rac_layer_tail_fwd(const void *const *acts, const void *const *weights, int 
                        int64_t partial_stride, int B, int Q, int T, int num_classes, int code_size,
                        float num_ray, float eps, void *stream);
 
-/* Row-wise  out = [relu]( LayerNorm( sum_{s<num_partials} a[s] + residual + bias ) * gamma + beta ).
- * Replaces the add / bias / split-K reduce + nn.LayerNorm (+ ReLU) launch groups of the decoder layer
- * (models/racformer_transformer.py:170-177, 199-205, 246-258).  a: device f32 [num_partials][rows][dim]
- * (partial s at a + s*partial_stride); residual [rows][dim], bias [dim]: optional (NULL); dim % 4 == 0, <= 1024. */
-int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, const float *residual,
-                   const float *bias, const float *gamma, const float *beta, float *out, int rows, int dim,
-                   float eps, int relu, void *stream);
+/* Row-wise  out = [relu]( LayerNorm( sum_{s<num_partials} a[s] + residual + bias ) * gamma + beta ) [+ post_residual].
+ * Replaces the add / bias / split-K reduce + nn.LayerNorm (+ ReLU) (+ add) launch groups of the decoder layer
+ * (models/racformer_transformer.py:170-177, 199-205, 243-258).  a: device f32, row r of partial s at
+ * a + s*partial_stride + r*ld_a; residual / post_residual [rows][dim], bias [dim]: optional (NULL); out row r at
+ * out + r*ld_out (so results can land in a column slice of a wider buffer); dim % 4 == 0, <= 1024. */
+int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, const float *residual,
+                   const float *bias, const float *gamma, const float *beta, const float *post_residual,
+                   float *out, int ld_out, int rows, int dim, float eps, int relu, void *stream);
+
+/* Position-encoder head  out = relu(LayerNorm(W x + b))  for the 3-wide box input
+ * (models/racformer_transformer.py:170-173); x row r at x + r*ld_x (3 values), weight [256,3], out [rows,256]. */
+int rac_pe_head_fwd(const float *x, int ld_x, const float *weight, const float *bias, const float *gamma,
+                    const float *beta, float *out, int rows, int dim, float eps, void *stream);
 
 /* Box refinement tail of a decoder layer: refine_bbox + velocity / time_diff + theta_d2xy of the emitted
  * boxes (models/racformer_transformer.py:230-236, :265-269, :134; models/bbox/utils.py:82-90).

@@ -3,8 +3,8 @@
 // The decoder layer applies LayerNorm(256) ten times per layer, always right after an add
 // (x + attn, x + proj, f + ffn, ...; models/racformer_transformer.py:170-177,199-205,246-258) or
 // followed by a ReLU (position encoder, cls branch).  In torch each is 2-4 launches; here
-//     out = [relu]( LN( sum_s a[s] + residual + bias ) * gamma + beta )
-// is one launch: one wave64 per row, 16-byte loads, two-pass mean / variance in registers.
+//     out = [relu]( LN( sum_s a[s] + residual + bias ) * gamma + beta ) [+ post_residual]
+// is one launch (input / output rows may be column slices of wider buffers: ld_a, ld_out): one wave64 per row, 16-byte loads, two-pass mean / variance in registers.
 #include "rac_common.h"
 
 #define ALN_MAX_V 4 /* float4 per lane: dim <= 1024 */
@@ -17,10 +17,11 @@ __device__ __forceinline__ float aln_wave_sum(float v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a, int S, long pstride,
+__global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a, int S, long pstride, int ld_a,
                                                      const float *__restrict__ residual, const float *__restrict__ bias,
                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                     float *__restrict__ out, int rows, int dim, float eps, int relu)
+                                                     const float *__restrict__ post, float *__restrict__ out, int ld_out,
+                                                     int rows, int dim, float eps, int relu)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -34,9 +35,9 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
         const int c = lane + 64 * k;
         x[k] = (rac_f4){0.f, 0.f, 0.f, 0.f};
         if (c < nv) {
-            rac_f4 v = rac_ld4(a + (size_t)row * dim + c * 4);
+            rac_f4 v = rac_ld4(a + (size_t)row * ld_a + c * 4);
             for (int s = 1; s < S; ++s) {
-                const rac_f4 w = rac_ld4(a + (size_t)s * pstride + (size_t)row * dim + c * 4);
+                const rac_f4 w = rac_ld4(a + (size_t)s * pstride + (size_t)row * ld_a + c * 4);
                 v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
             }
             if (bias) {
@@ -73,21 +74,64 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
             if (relu) {
                 y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
             }
-            *reinterpret_cast<rac_f4 *>(out + (size_t)row * dim + c * 4) = y;
+            if (post) {
+                const rac_f4 w = rac_ld4(post + (size_t)row * dim + c * 4);
+                y.x += w.x; y.y += w.y; y.z += w.z; y.w += w.w;
+            }
+            *reinterpret_cast<rac_f4 *>(out + (size_t)row * ld_out + c * 4) = y;
         }
     }
 }
 
-extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, const float *residual,
-                              const float *bias, const float *gamma, const float *beta, float *out, int rows, int dim,
-                              float eps, int relu, void *stream)
+// position-encoder head: out = relu(LN(W x + b)) for a 3-wide input (models/racformer_transformer.py:170-173);
+// a GEMM with K=3 is pure launch overhead, so the three FMAs per output are done here.
+__global__ __launch_bounds__(256) void pe_head_kernel(const float *__restrict__ x, int ld_x, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, float *__restrict__ out, int rows, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows)
+        return;
+    const float x0 = x[(size_t)row * ld_x], x1 = x[(size_t)row * ld_x + 1], x2 = x[(size_t)row * ld_x + 2];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + j;
+        v[j] = W[c * 3] * x0 + W[c * 3 + 1] * x1 + W[c * 3 + 2] * x2 + bias[c];
+    }
+    const float mean = aln_wave_sum((v[0] + v[1]) + (v[2] + v[3])) / 256.f;
+    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    const float rstd = 1.f / sqrtf(aln_wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 256.f + eps);
+    const rac_f4 g = rac_ld4(gamma + lane * 4), b = rac_ld4(beta + lane * 4);
+    rac_f4 y = {fmaxf(d0 * rstd * g.x + b.x, 0.f), fmaxf(d1 * rstd * g.y + b.y, 0.f), fmaxf(d2 * rstd * g.z + b.z, 0.f),
+                fmaxf(d3 * rstd * g.w + b.w, 0.f)};
+    *reinterpret_cast<rac_f4 *>(out + (size_t)row * 256 + lane * 4) = y;
+}
+
+extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, const float *residual,
+                              const float *bias, const float *gamma, const float *beta, const float *post_residual,
+                              float *out, int ld_out, int rows, int dim, float eps, int relu, void *stream)
 {
     RAC_CHECK_ARG(rows >= 0 && dim >= 4 && dim % 4 == 0 && dim <= 256 * ALN_MAX_V, "rac_add_ln_fwd: dim=%d (multiple of 4, <= %d)", dim, 256 * ALN_MAX_V);
     RAC_CHECK_ARG(num_partials >= 1, "rac_add_ln_fwd: num_partials=%d", num_partials);
+    RAC_CHECK_ARG(ld_a >= dim && ld_out >= dim && ld_a % 4 == 0 && ld_out % 4 == 0, "rac_add_ln_fwd: row strides ld_a=%d ld_out=%d", ld_a, ld_out);
     if (rows == 0)
         return 0;
     RAC_CHECK_ARG(a && gamma && beta && out, "rac_add_ln_fwd: null pointer");
     hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, num_partials,
-                       (long)partial_stride, residual, bias, gamma, beta, out, rows, dim, eps, relu);
+                       (long)partial_stride, ld_a, residual, bias, gamma, beta, post_residual, out, ld_out, rows, dim, eps, relu);
     return rac_launch_status("rac_add_ln_fwd");
+}
+
+extern "C" int rac_pe_head_fwd(const float *x, int ld_x, const float *weight, const float *bias, const float *gamma,
+                               const float *beta, float *out, int rows, int dim, float eps, void *stream)
+{
+    RAC_CHECK_ARG(dim == 256 && rows >= 0 && ld_x >= 3, "rac_pe_head_fwd: dim=%d (built for 256), ld_x=%d", dim, ld_x);
+    if (rows == 0)
+        return 0;
+    RAC_CHECK_ARG(x && weight && bias && gamma && beta && out, "rac_pe_head_fwd: null pointer");
+    hipLaunchKernelGGL(pe_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld_x, weight, bias, gamma,
+                       beta, out, rows, eps);
+    return rac_launch_status("rac_pe_head_fwd");
 }

@@ -83,7 +83,8 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
 
 
 def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits, queue_logits, time_diff,
-                       num_frames, num_heads, num_points, depth_num, pc_range, d_region, debug=False, box_table=None):
+                       num_frames, num_heads, num_points, depth_num, pc_range, d_region, debug=False, box_table=None,
+                       out=None):
     """value [B*T, H*W, heads, 64] -> [B,Q,heads*64] (frame-fused, before output_proj)."""
     _lib.require_gpu(value, query_bbox, time_diff, what="bev_sampling_fused")
     B, Q, _ = query_bbox.shape
@@ -98,7 +99,10 @@ def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits,
     p_qu, ld_qu = _rows(queue_logits, T, "bev_sampling_fused(queue_logits)")
     if box_table is None:
         box_table = box_prep(query_bbox, pc_range)
-    out = torch.empty(B, Q, Hn * 64, device=query_bbox.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, Q, Hn * 64, device=query_bbox.device, dtype=torch.float32)
+    elif not out.is_contiguous() or tuple(out.shape) != (B, Q, Hn * 64):
+        raise RuntimeError("bev_sampling_fused: out must be a contiguous [B,Q,heads*64] tensor")
     loc_out = torch.empty(B, Q, Hn, T, P, 2, device=out.device, dtype=torch.float32) if debug else None
     pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
     ev = _lib.timer.record("bev_sampling_fwd") if _lib.timer is not None else None
@@ -169,23 +173,55 @@ def refine_fused(proposal, delta, time_diff_safe, num_ray):
     return pred, xy
 
 
-def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1):
-    """[relu](LayerNorm(sum_s a[s] + residual + bias)) with ``norm`` an nn.LayerNorm; a is [..., dim]
-    (or [S, ..., dim] with num_partials=S).  One launch."""
-    a = a.contiguous()
-    _lib.require_gpu(a, what="add_ln")
+def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=None, out=None):
+    """[relu](LayerNorm(sum_s a[s] + residual + bias)) [+ post] with ``norm`` an nn.LayerNorm; a is [..., dim]
+    (unit inner stride; rows may be a column slice of a wider tensor) or [S, ..., dim] with num_partials=S.
+    ``out``: optional destination (may itself be a column slice).  One launch."""
+    _lib.require_gpu(norm.weight, what="add_ln")
     dim = a.shape[-1]
-    shape = a.shape[1:] if num_partials > 1 else a.shape
-    if residual is not None and residual.numel() == a.numel() // num_partials:
-        shape = residual.shape
-    rows = a.numel() // dim // num_partials
+    if num_partials > 1:
+        a = a.contiguous()
+        rows, ld_a, shape = a.numel() // dim // num_partials, dim, a.shape[1:]
+    else:
+        if a.stride(-1) != 1 or not a.is_cuda:
+            raise RuntimeError("add_ln: input must be a CUDA tensor with unit inner stride")
+        lead = a.shape[:-1]
+        rows, shape = int(torch.Size(lead).numel()), a.shape
+        ld_a = a.stride(-2) if a.dim() > 1 else dim
+        if a.dim() > 2 and a.stride(0) != a.shape[1] * a.stride(1):
+            raise RuntimeError("add_ln: rows must be equally strided")
     if residual is not None:
         residual = residual.contiguous()
-    out = torch.empty(shape, device=a.device, dtype=torch.float32)
-    rc = _lib.lib().rac_add_ln_fwd(_lib.ptr(a), num_partials, rows * dim, _lib.ptr(residual) if residual is not None else None,
+        if residual.numel() == rows * dim:
+            shape = residual.shape
+    if post is not None:
+        post = post.contiguous()
+    if out is None:
+        out = torch.empty(shape, device=a.device, dtype=torch.float32)
+        ld_out = dim
+    else:
+        if out.stride(-1) != 1 or out.shape[-1] != dim:
+            raise RuntimeError("add_ln: out must have unit inner stride and the normalised width")
+        ld_out = out.stride(-2)
+    rc = _lib.lib().rac_add_ln_fwd(_lib.ptr(a), num_partials, rows * dim, ld_a,
+                                   _lib.ptr(residual) if residual is not None else None,
                                    _lib.ptr(bias) if bias is not None else None, _lib.ptr(norm.weight), _lib.ptr(norm.bias),
-                                   _lib.ptr(out), rows, dim, float(norm.eps), int(relu), _lib.stream_ptr())
+                                   _lib.ptr(post) if post is not None else None, _lib.ptr(out), ld_out, rows, dim,
+                                   float(norm.eps), int(relu), _lib.stream_ptr())
     _lib.check(rc, "rac_add_ln_fwd")
+    return out
+
+
+def pe_head(x3, linear, norm):
+    """relu(LayerNorm(linear(x3))) for the 3-wide position-encoder input, one launch.  x3: [..., 3] view."""
+    if x3.stride(-1) != 1 or not x3.is_cuda:
+        raise RuntimeError("pe_head: input must be a CUDA tensor with unit inner stride")
+    rows = int(torch.Size(x3.shape[:-1]).numel())
+    out = torch.empty(x3.shape[:-1] + (linear.weight.shape[0],), device=x3.device, dtype=torch.float32)
+    rc = _lib.lib().rac_pe_head_fwd(_lib.ptr(x3), x3.stride(-2), _lib.ptr(linear.weight), _lib.ptr(linear.bias),
+                                    _lib.ptr(norm.weight), _lib.ptr(norm.bias), _lib.ptr(out), rows, linear.weight.shape[0],
+                                    float(norm.eps), _lib.stream_ptr())
+    _lib.check(rc, "rac_pe_head_fwd")
     return out
 
 

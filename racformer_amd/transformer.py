@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import LayerTailWeights, add_ln, bev_sampling_fused, layer_tail_fused, box_prep, mixing_fused, refine_fused, sampling4d_fused, sasa_fused
+from .fused import LayerTailWeights, add_ln, bev_sampling_fused, layer_tail_fused, pe_head, box_prep, mixing_fused, refine_fused, sampling4d_fused, sasa_fused
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -628,6 +628,12 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
                     wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=self.mixing.split_out_proj(),
                     sasa_w=self.self_attn.wide_in_proj(),
+                    bev_owt=torch.stack([self.sampling_radar_bev.attention.output_proj.weight.t(),
+                                         self.sampling_lss_bev.attention.output_proj.weight.t()]).contiguous(),
+                    bev_ob=torch.stack([self.sampling_radar_bev.attention.output_proj.bias,
+                                        self.sampling_lss_bev.attention.output_proj.bias])[:, None, :].contiguous(),
+                    c0r0_w=torch.cat([self.cls_branch[0].weight, self.reg_branch[0].weight], dim=0),
+                    c0r0_b=torch.cat([self.cls_branch[0].bias, self.reg_branch[0].bias], dim=0),
                     **({"side_stream": self._side_stream(radar_value.device)} if radar_value.is_cuda else {}),
                     **({"tail": LayerTailWeights(self)} if self.fused and self.tail_kernel and radar_value.is_cuda
                        and self.embed_dims == 256 and self.code_size == 10 and self.num_classes <= 16 else {}))
@@ -640,9 +646,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
         qb = query_bbox.contiguous()
         pe = self.position_encoder
-        h = add_ln(pe[0](qb[..., :3]), pe[1], relu=True)
-        query_pos = add_ln(pe[3](h), pe[4], relu=True)
-        x = query_feat + query_pos
+        h = pe_head(qb[..., :3], pe[0], pe[1])                         # relu(LN(Linear(3->256)))
+        x = add_ln(pe[3](h), pe[4], relu=True, post=query_feat)       # query_feat + relu(LN(Linear(h)))
         # scale-adaptive self-attention
         p = self.self_attn.attention.attn
         E = self.embed_dims
@@ -669,12 +674,14 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
         r_off, r_ray, r_sc, r_qu = lin[3:7]
         l_off, l_ray, l_sc, l_qu = lin[7:11]
-        bev_r = bev_sampling_fused(
-            prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff, rb.num_frames,
-            rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region, box_table=table)
-        bev_l = bev_sampling_fused(
-            prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff, lb.num_frames,
-            lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region, box_table=table)
+        B, Q = x1.shape[:2]
+        bev = torch.empty(2, B, Q, E, device=x1.device, dtype=torch.float32)
+        bev_sampling_fused(prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff,
+                           rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region,
+                           box_table=table, out=bev[0])
+        bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
+                           lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
+                           box_table=table, out=bev[1])
         sampled_feat = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=lin[0:3],
                                      box_table=table)
         # adaptive mixing: generator GEMM -> MFMA kernel -> split-K partial products of out_proj
@@ -683,26 +690,32 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], params)
         if stages is None and self.tail_kernel and "tail" in prepared:
             # everything that remains of the layer in one launch (rac_layer_tail_fwd)
-            x3, cls_score, bbox_pred, bbox_xy = layer_tail_fused(prepared["tail"], x1, bev_r, bev_l, partials, qb,
+            x3, cls_score, bbox_pred, bbox_xy = layer_tail_fused(prepared["tail"], x1, bev[0], bev[1], partials, qb,
                                                                  meta["time_diff_safe"], self.num_ray)
             self.last_bbox_xy = bbox_xy
             return x3, cls_score, bbox_pred
-        r_proj = rb.attention.output_proj(bev_r)
-        l_proj = lb.attention.output_proj(bev_l)
-        query_radar_feat = add_ln(r_proj, self.norm_radar_bev, residual=x1)
-        query_lss_feat = add_ln(l_proj, self.norm_lss_bev, residual=x1)
-        x2 = add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0])
-        f = add_ln(self.fusion(torch.cat((x2, query_radar_feat, query_lss_feat), dim=-1)), self.norm_fusion)
+        # both BEV output projections as one batched GEMM; the three normalised branches land directly in the
+        # [x2 | radar | lss] buffer the fusion Linear reads (no torch.cat)
+        proj = torch.baddbmm(prepared["bev_ob"], bev.view(2, B * Q, E), prepared["bev_owt"]).view(2, B, Q, E)
+        cat = torch.empty(B, Q, 3 * E, device=x1.device, dtype=torch.float32)
+        add_ln(proj[0], self.norm_radar_bev, residual=x1, out=cat[..., E:2 * E])
+        add_ln(proj[1], self.norm_lss_bev, residual=x1, out=cat[..., 2 * E:])
+        add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0],
+               out=cat[..., :E])
+        f = add_ln(self.fusion(cat), self.norm_fusion)
         ffn_lin = self.ffn.layers[1](F.relu(self.ffn.layers[0][0](f)))
         x3 = add_ln(ffn_lin, self.norm3, residual=f)
-        cb = self.cls_branch
-        c = add_ln(cb[0](x3), cb[1], relu=True)
+        # first Linear of the cls and reg branches as one GEMM
+        cb, rg = self.cls_branch, self.reg_branch
+        c0r0 = F.linear(x3, prepared["c0r0_w"], prepared["c0r0_b"])
+        c = add_ln(c0r0[..., :E], cb[1], relu=True)
         c = add_ln(cb[3](c), cb[4], relu=True)
         cls_score = cb[6](c)
-        bbox_pred, bbox_xy = refine_fused(qb, self.reg_branch(x3), meta["time_diff_safe"], self.num_ray)
+        delta = rg[4](F.relu(rg[2](F.relu(c0r0[..., E:]))))
+        bbox_pred, bbox_xy = refine_fused(qb, delta, meta["time_diff_safe"], self.num_ray)
         if stages is not None:
-            stages.update(position_encoder=query_pos, self_attn=x + attn, sampling_radar_bev=r_proj + x1,
-                          sampling_lss_bev=l_proj + x1, sampling=sampled_feat,
+            stages.update(position_encoder=x - query_feat, self_attn=x + attn, sampling_radar_bev=proj[0] + x1,
+                          sampling_lss_bev=proj[1] + x1, sampling=sampled_feat,
                           mixing=x1 + partials.sum(0).view_as(x1) + self.mixing.out_proj.bias, ffn=f + ffn_lin)
         self.last_bbox_xy = bbox_xy
         return x3, cls_score, bbox_pred

@@ -34,15 +34,11 @@ class QuickCumsumCuda(torch.autograd.Function):
     @staticmethod
     def backward(ctx, out_grad):
         ranks_bev, depth, feat, ranks_feat, ranks_depth = ctx.saved_tensors
-        # regroup the points by feature index (bev_pool.py:50-63)
-        order = ranks_feat.argsort()
+        # The backward kernel wants the points grouped by the feature cell they read (what bev_pool.py:50-63
+        # prepares): a stable sort by ranks_feat, then run lengths of equal keys.
+        order = torch.argsort(ranks_feat, stable=True)
         ranks_feat, ranks_depth, ranks_bev = ranks_feat[order], ranks_depth[order], ranks_bev[order]
-        kept = torch.ones(ranks_bev.shape[0], device=ranks_bev.device, dtype=torch.bool)
-        kept[1:] = ranks_feat[1:] != ranks_feat[:-1]
-        interval_starts_bp = torch.where(kept)[0].int()
-        interval_lengths_bp = torch.zeros_like(interval_starts_bp)
-        interval_lengths_bp[:-1] = interval_starts_bp[1:] - interval_starts_bp[:-1]
-        interval_lengths_bp[-1] = ranks_bev.shape[0] - interval_starts_bp[-1]
+        interval_starts_bp, interval_lengths_bp = intervals_from_ranks(ranks_feat)
         ranks_depth, ranks_feat, ranks_bev = ranks_depth.contiguous(), ranks_feat.contiguous(), ranks_bev.contiguous()
         depth_grad = depth.new_zeros(depth.shape)
         feat_grad = feat.new_zeros(feat.shape)
@@ -62,13 +58,12 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
-def intervals_from_ranks(ranks_bev):
-    """interval_starts / interval_lengths of consecutive equal ranks_bev (as the reference's own test builds
-    them, bev_pool.py:158-166)."""
-    kept = torch.ones(ranks_bev.shape[0], device=ranks_bev.device, dtype=torch.bool)
-    kept[1:] = ranks_bev[1:] != ranks_bev[:-1]
-    starts = torch.where(kept)[0].int()
-    lengths = torch.zeros_like(starts)
-    lengths[:-1] = starts[1:] - starts[:-1]
-    lengths[-1] = ranks_bev.shape[0] - starts[-1]
-    return starts, lengths
+def intervals_from_ranks(ranks):
+    """(starts, lengths), int32, of the runs of equal consecutive values in ``ranks`` -- the interval tables the
+    pooling kernels consume (the reference's own test builds them the same way, bev_pool.py:158-166)."""
+    if ranks.numel() == 0:
+        empty = torch.zeros(0, dtype=torch.int32, device=ranks.device)
+        return empty, empty.clone()
+    _, counts = torch.unique_consecutive(ranks, return_counts=True)
+    starts = torch.cumsum(counts, dim=0) - counts
+    return starts.int(), counts.int()

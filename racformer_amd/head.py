@@ -84,13 +84,13 @@ class RaCFormer_head(nn.Module):
         self.transformer.init_weights()
 
     def generate_points(self):
-        """racformer_head.py:69-79"""
-        num_angles = self.num_query // self.num_clusters
-        angles = torch.linspace(0, 1, num_angles + 1)[:-1]
-        distances = torch.linspace(0, 1, self.num_clusters + 2, dtype=torch.float)[1:-1]
-        angles = angles.view(num_angles, 1).expand(num_angles, self.num_clusters)
-        distances = distances.view(1, self.num_clusters).expand(num_angles, self.num_clusters)
-        return torch.cat([angles[..., None], distances[..., None]], dim=-1).flatten(0, 1)
+        """Polar query grid of racformer_head.py:69-79: ``num_query // num_clusters`` rays (theta in [0,1), 0
+        excluded at the top end) times ``num_clusters`` ranges strictly inside (0,1); row-major (ray, cluster)."""
+        rays = self.num_query // self.num_clusters
+        theta = torch.linspace(0, 1, rays + 1)[:rays]
+        rng = torch.linspace(0, 1, self.num_clusters + 2, dtype=torch.float)[1:self.num_clusters + 1]
+        grid = torch.stack(torch.meshgrid(theta, rng, indexing="ij"), dim=-1)       # [rays, clusters, 2]
+        return grid.reshape(-1, 2)
 
     def forward(self, mlvl_feats, lss_bev_feats, radar_bev_feats, img_metas):
         """racformer_head.py:82-134, eval branch of prepare_for_dn_input (:142-145, :241-245)."""

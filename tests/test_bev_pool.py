@@ -19,13 +19,8 @@ def _known(golden_dir, device="cpu"):
 
 
 def _intervals(rb):
-    kept = torch.ones(rb.shape[0], dtype=torch.bool, device=rb.device)
-    kept[1:] = rb[1:] != rb[:-1]
-    starts = torch.where(kept)[0].int()
-    lengths = torch.zeros_like(starts)
-    lengths[:-1] = starts[1:] - starts[:-1]
-    lengths[-1] = rb.shape[0] - starts[-1]
-    return starts, lengths
+    _, counts = torch.unique_consecutive(rb, return_counts=True)
+    return (torch.cumsum(counts, 0) - counts).int(), counts.int()
 
 
 def test_oracle_known_answer(golden_dir):

@@ -184,6 +184,23 @@ def main():
     achieved = b_alg / (msmv_ms * 1e-3) / 1e9 if msmv_ms else None
     traffic, traffic_src = pmc_traffic("sampling4d_c64_kernel")
 
+    # dense contractions of the path on the matrix cores: achieved fp32 rate against the 157.3 TFLOP/s fp32-MFMA
+    # peak of gfx950 (exact-fp32 v_mfma_f32_*_f32; no xf32 on this chip) -- FLOPs are algorithmic, per launch
+    Qn, E, G_, C_ = cfg.num_query, cfg.embed_dims, cfg.num_groups, cfg.channels
+    Pin = cfg.num_points * cfg.num_frames * cfg.img_depth_num
+    gen_cols = G_ * (C_ * C_ + 128 * Pin)
+    mfma = {}
+    for key, name, flops in (
+            ("mixing_fwd", "mixing_c64_kernel (hand-written, v_mfma_f32_16x16x4_f32)", 2.0 * Qn * G_ * (Pin * C_ * C_ + 128 * Pin * C_)),
+            ("mixing_generator_gemm", "parameter_generator GEMM (rocBLAS)", 2.0 * Qn * E * gen_cols),
+            ("mixing_out_proj_gemm", "out_proj split-K batched GEMM (rocBLAS)", 2.0 * Qn * (G_ * 128 * C_) * E)):
+        ms = timer.mean_ms(key)
+        if ms:
+            tf = flops / (ms * 1e-3) / 1e12
+            mfma[key] = {"kernel": name, "avg_launch_ms": ms, "gflop_per_launch": flops / 1e9, "achieved_tflops": tf,
+                         "peak_tflops": 157.3, "frac": tf / 157.3}
+    sasa_ms = timer.mean_ms("sasa_fwd")
+
     result = {
         "metric": "samples/sec (6-cam 704x256, 900 queries, f8)" if args.config == "f8"
                   else "samples/sec (3-cam 704x256, 900 queries, f8)",
@@ -205,7 +222,8 @@ def main():
                      "avg_launch_ms": msmv_ms, "launches_per_step": len(cap.captured),
                      "algorithmic_bytes_per_launch": b_alg, "algorithmic_bytes_all_in_range": b_alg_closed,
                      "in_range_fraction_per_layer": in_frac,
-                     "bev_sampling_avg_launch_ms": msda_ms},
+                     "bev_sampling_avg_launch_ms": msda_ms, "sasa_avg_launch_ms": sasa_ms},
+        "mfma_fp32": mfma,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -500,11 +500,23 @@ class AdaptiveMixing(nn.Module):
         is inner_forward's result (the caller folds that sum into its LayerNorm kernel).  ``params``:
         the generator output if the caller already produced it (on a side stream)."""
         B, Q, G, P, C = x.shape
+        timer = _lib.timer
         if params is None:
+            ev = timer.record("mixing_generator_gemm") if timer is not None else None
+            if ev:
+                ev[0].record()
             params = self.parameter_generator(query)
+            if ev:
+                ev[1].record()
         out = mixing_fused(x.contiguous(), params, P, G, self.out_points)
         S_, N, k = out_proj_split.shape
-        return torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
+        ev = timer.record("mixing_out_proj_gemm") if timer is not None else None
+        if ev:
+            ev[0].record()
+        partials = torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
+        if ev:
+            ev[1].record()
+        return partials
 
     def forward(self, x, query, out_proj_split=None):
         B, Q, G, P, C = x.shape

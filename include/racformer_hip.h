@@ -136,9 +136,11 @@ int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float
  * (models/racformer_transformer.py:296-335); in_proj / out_proj remain library GEMMs.
  *   qkv : device f32, token row (b,q) at qkv + (b*Q+q)*ld_qkv holding q|k|v, each [heads, dim]
  *   tau : device f32, rows of `heads` values, stride ld_tau (gen_tau Linear output)
- *   out : device f32 [B,Q,heads*dim];  pc_range: HOST (6).  dim must be 32. */
-int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, float *out, int ld_qkv,
-                 int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream);
+ *   box_table : optional device f32 [B,Q,8] from rac_box_prep_fwd for the same boxes (NULL: centres computed here)
+ *   out : device f32 [B,Q,heads*dim];  pc_range: HOST (6).  dim must be 32.  Q <= 1024: QK^T and PV run on
+ *   v_mfma_f32_16x16x4_f32 (exact fp32); larger Q: an LDS-tiled fp32 VALU kernel. */
+int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, const float *box_table, float *out,
+                 int ld_qkv, int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream);
 
 /* Everything after the three sampling kernels of a decoder layer in one launch (exact-fp32 MFMA row chain):
  * BEV output projections + norms, AdaptiveMixing's split-K reduction + norm2, fusion + norm, FFN + norm3,

@@ -33,7 +33,7 @@ SIGNATURES = {
     "rac_pe_head_fwd": (_i, [_vp, _i] + [_vp] * 5 + [_i, _i, _f, _vp]),
     "rac_refine_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_f, _vp]),
     "rac_mixing_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_f, _vp]),
-    "rac_sasa_fwd": (_i, [_vp] * 4 + [_i] * 6 + [_vp, _vp]),
+    "rac_sasa_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
     "rac_bev_sampling_fwd": (_i, [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
 }
 

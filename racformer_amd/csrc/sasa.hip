@@ -25,6 +25,7 @@ struct SasaArgs {
     const float *qkv;   // [B,Q,3,H,d]  (in_proj output)
     const float *tau;   // [B,Q,H], row stride ld_tau
     const float *qbox;  // [B,Q,10]
+    const float *box;   // optional [B,Q,8] from rac_box_prep_fwd (cx, cy, ...): skips the trig prologue
     float *out;         // [B,Q,H*d]
     float pc[6];
     int B, Q, H, ld_tau, ld_qkv;
@@ -175,23 +176,186 @@ __global__ __launch_bounds__(256) void sasa_d32_kernel(const SasaArgs a)
     }
 }
 
-extern "C" int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, float *out, int ld_qkv,
-                            int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream)
+// ---------------------------------------------------------------------------------------------------
+// Matrix-core version (default): QK^T and PV on v_mfma_f32_16x16x4_f32 (exact fp32).
+// Workgroup = 16 queries of one (batch, head); its 4 waves take the 16-key tiles round-robin.
+//   S^T tile [16 keys x 16 queries] = K_tile (A operand) . Q^T (B operand): 8 MFMAs.  With the k index of
+//   a group of four steps assigned as k = 16u + 4*lk + i (see rowmlp.h) every operand is a 16-byte load.
+//   The accumulator then holds S^T[key = 4*lk + r][query = li] -- exactly the B-operand layout of the
+//   second product O^T[32 ch x 16 queries] = V^T (A operand) . P^T (B operand), so the probabilities go
+//   from the first product's accumulators into the second product's operands without leaving registers.
+//   Softmax statistics are per query = per lane column: a register reduction, two DPP steps over lk and
+//   one LDS exchange between the four waves.
+typedef float sasa_f4 __attribute__((ext_vector_type(4)));
+#define SASA_NT 16 /* key tiles per wave: Q <= 4*16*16 = 1024 */
+
+__global__ __launch_bounds__(256) void sasa_mfma_kernel(const SasaArgs a)
+{
+    extern __shared__ float smem[];
+    float *scen = smem;                       // [Q][2] key centres (metres)
+    float *sred = smem + 2 * ((a.Q + 1) & ~1);  // [4 waves][16] max, then [4][16] sum
+    float *so = sred + 2 * 4 * 16;            // [4 waves][32 ch][16 queries]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    int bid = blockIdx.x;
+    const int rb = bid % a.row_blocks; bid /= a.row_blocks;
+    const int h = bid % a.H;
+    const int b = bid / a.H;
+    const int Q = a.Q, H = a.H;
+    const size_t tok = (size_t)b * Q;
+    const int ld = a.ld_qkv;
+
+    for (int j = tid; j < Q; j += 256) {
+        if (a.box) {
+            scen[2 * j] = a.box[((size_t)b * Q + j) * 8];
+            scen[2 * j + 1] = a.box[((size_t)b * Q + j) * 8 + 1];
+        } else {
+            const float *qb = a.qbox + ((size_t)b * Q + j) * 10;
+            const float ang = qb[0] * SASA_TWO_PI, rad = qb[1] * 65.0f;
+            const float xn = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f);
+            const float yn = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f);
+            scen[2 * j] = xn * (a.pc[3] - a.pc[0]) + a.pc[0];
+            scen[2 * j + 1] = yn * (a.pc[4] - a.pc[1]) + a.pc[1];
+        }
+    }
+    // this lane's query column
+    const int qi = rb * SASA_ROWS + li;
+    const int qc = qi < Q ? qi : Q - 1;
+    const float scale = 0.17677669529663687f;
+    rac_f4 qb4[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qb4[u] = rac_ld4(a.qkv + (tok + qc) * ld + h * SASA_D + 16 * u + 4 * lk);
+        qb4[u].x *= scale; qb4[u].y *= scale; qb4[u].z *= scale; qb4[u].w *= scale;
+    }
+    const float tau = a.tau[(tok + qc) * a.ld_tau + h];
+    __syncthreads();
+    const float cqx = scen[2 * qc], cqy = scen[2 * qc + 1];
+
+    const int ntiles = (Q + 15) >> 4;
+    sasa_f4 sc[SASA_NT];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < SASA_NT; ++jt) {
+        const int tile = wave + 4 * jt;
+        sc[jt] = (sasa_f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (tile < ntiles) {
+            const int key = tile * 16 + li;
+            const int kc = key < Q ? key : Q - 1;
+            const float *kp = a.qkv + (tok + kc) * ld + (H + h) * SASA_D + 4 * lk;
+            const rac_f4 k0 = rac_ld4(kp), k1 = rac_ld4(kp + 16);
+            sasa_f4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qb4[0].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qb4[0].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qb4[0].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qb4[0].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qb4[1].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qb4[1].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qb4[1].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qb4[1].w, acc, 0, 0, 0);
+            // acc[r] = (q_query . k_key)/sqrt(d) for key = tile*16 + 4*lk + r, query = li; add the distance mask
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = tile * 16 + 4 * lk + r;
+                if (kk < Q) {
+                    const float dx = cqx - scen[2 * kk], dy = cqy - scen[2 * kk + 1];
+                    const float v = acc[r] - sqrtf(dx * dx + dy * dy) * tau;
+                    sc[jt][r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+            }
+        }
+    }
+    // per-query max: over lk inside the wave, then over the four waves
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    if (lk == 0)
+        sred[wave * 16 + li] = mloc;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(sred[li], sred[16 + li]), fmaxf(sred[32 + li], sred[48 + li]));
+    float lsum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < SASA_NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = (sc[jt][r] == -INFINITY) ? 0.f : expf(sc[jt][r] - m);
+            sc[jt][r] = p;
+            lsum += p;
+        }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (lk == 0)
+        sred[64 + wave * 16 + li] = lsum;
+    // O^T[ch][query] = sum_keys V[key][ch] * P^T[key][query]
+    sasa_f4 oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int jt = 0; jt < SASA_NT; ++jt) {
+        const int tile = wave + 4 * jt;
+        if (tile < ntiles) {
+            float va[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = tile * 16 + 4 * lk + i;
+                const int kc = key < Q ? key : Q - 1;
+                const float *vp = a.qkv + (tok + kc) * ld + (2 * H + h) * SASA_D;
+                va[0][i] = vp[li];
+                va[1][i] = vp[16 + li];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[0][i], sc[jt][i], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[1][i], sc[jt][i], oacc[1], 0, 0, 0);
+            }
+        }
+    }
+    // combine the four waves: so[wave][ch][query]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            so[(wave * 32 + 16 * c + 4 * lk + r) * 16 + li] = oacc[c][r];
+    __syncthreads();
+    {
+        const int qq = tid >> 4, cp = (tid & 15) * 2;   // query within the tile, channel pair
+        const int qrow = rb * SASA_ROWS + qq;
+        if (qrow < Q) {
+            const float l = (sred[64 + qq] + sred[64 + 16 + qq]) + (sred[64 + 32 + qq] + sred[64 + 48 + qq]);
+            float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                o0 += so[(w * 32 + cp) * 16 + qq];
+                o1 += so[(w * 32 + cp + 1) * 16 + qq];
+            }
+            *reinterpret_cast<float2 *>(a.out + (tok + qrow) * (size_t)(H * SASA_D) + h * SASA_D + cp) =
+                make_float2(o0 / l, o1 / l);
+        }
+    }
+}
+
+extern "C" int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, const float *box_table,
+                            float *out, int ld_qkv, int ld_tau, int B, int Q, int heads, int dim, const float *pc_range,
+                            void *stream)
 {
     RAC_CHECK_ARG(dim == SASA_D, "rac_sasa_fwd: head dim %d (the kernel is built for %d)", dim, SASA_D);
     RAC_CHECK_ARG(B >= 0 && Q >= 0 && heads >= 1 && ld_tau >= heads && ld_qkv >= 3 * heads * dim && ld_qkv % 4 == 0, "rac_sasa_fwd: bad sizes B=%d Q=%d heads=%d", B, Q, heads);
-    RAC_CHECK_ARG((size_t)Q * 2 * sizeof(float) <= 64 * 1024, "rac_sasa_fwd: Q=%d too large for the LDS centre table", Q);
+    RAC_CHECK_ARG((size_t)Q * 2 * sizeof(float) <= 48 * 1024, "rac_sasa_fwd: Q=%d too large for the LDS centre table", Q);
     if (B == 0 || Q == 0)
         return 0;
     RAC_CHECK_ARG(qkv && tau && query_bbox && out && pc_range, "rac_sasa_fwd: null pointer");
     SasaArgs a;
-    a.qkv = qkv; a.tau = tau; a.qbox = query_bbox; a.out = out;
+    a.qkv = qkv; a.tau = tau; a.qbox = query_bbox; a.box = box_table; a.out = out;
     for (int i = 0; i < 6; ++i)
         a.pc[i] = pc_range[i];
     a.B = B; a.Q = Q; a.H = heads; a.ld_tau = ld_tau; a.ld_qkv = ld_qkv;
     a.row_blocks = (Q + SASA_ROWS - 1) / SASA_ROWS;
     const int nb = B * heads * a.row_blocks;
-    const size_t lds = ((size_t)2 * ((Q + 1) & ~1) + 2 * SASA_TILE * SASA_KS) * sizeof(float);
-    hipLaunchKernelGGL(sasa_d32_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, a);
+    const size_t cen = (size_t)2 * ((Q + 1) & ~1);
+    if (Q <= 4 * SASA_NT * 16) {
+        const size_t lds = (cen + 2 * 4 * 16 + 4 * 32 * 16) * sizeof(float);
+        hipLaunchKernelGGL(sasa_mfma_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        const size_t lds = (cen + 2 * SASA_TILE * SASA_KS) * sizeof(float);
+        hipLaunchKernelGGL(sasa_d32_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, a);
+    }
     return rac_launch_status("rac_sasa_fwd");
 }

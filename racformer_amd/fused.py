@@ -118,7 +118,7 @@ def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits,
     return (out, loc_out) if debug else out
 
 
-def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range):
+def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range, box_table=None):
     """qkv [B,Q,3*E] (q|k|v, each [heads, E/heads]; may be a column slice), tau [B,Q,heads] ->
     attention output [B,Q,E] before out_proj."""
     _lib.require_gpu(query_bbox, what="sasa_fused")
@@ -131,7 +131,8 @@ def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range):
     ev = _lib.timer.record("sasa_fwd") if _lib.timer is not None else None
     if ev:
         ev[0].record()
-    rc = _lib.lib().rac_sasa_fwd(p_qkv, p_tau, _lib.ptr(query_bbox), _lib.ptr(out), ld_qkv, ld_tau, B, Q, num_heads,
+    rc = _lib.lib().rac_sasa_fwd(p_qkv, p_tau, _lib.ptr(query_bbox), _lib.ptr(box_table) if box_table is not None else None,
+                                 _lib.ptr(out), ld_qkv, ld_tau, B, Q, num_heads,
                                  E // num_heads, pc, _lib.stream_ptr())
     if ev:
         ev[1].record()

@@ -663,8 +663,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # scale-adaptive self-attention
         p = self.self_attn.attention.attn
         E = self.embed_dims
+        table = box_prep(qb, self.pc_range)      # decode_bbox(theta_d2xy(.)) once for SASA and the 3 sampling kernels
         lin = F.linear(x, prepared["sasa_w"][0], prepared["sasa_w"][1])
-        attn = p.out_proj(sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], qb, self.self_attn.num_heads, self.pc_range))
+        attn = p.out_proj(sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], qb, self.self_attn.num_heads, self.pc_range,
+                                     box_table=table))
         x1 = add_ln(attn, self.norm1, residual=x)
         # The 30-GFLOP parameter generator of AdaptiveMixing needs only x1.  It is MFMA-bound while the three
         # sampling kernels are memory / L2-bound, so it runs on a second HIP stream beside them.
@@ -682,7 +684,6 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             params.record_stream(main)
         # the three sampling modules: one wide GEMM, one box table, three fused kernels
         lin = F.linear(x1, prepared["wide_w"], prepared["wide_b"]).split(prepared["wide_widths"], dim=-1)
-        table = box_prep(qb, self.pc_range)
         rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
         r_off, r_ray, r_sc, r_qu = lin[3:7]
         l_off, l_ray, l_sc, l_qu = lin[7:11]

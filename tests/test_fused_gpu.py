@@ -167,3 +167,24 @@ def test_layer_tail_kernel_matches_op_chain(cfg):
     # layer 0 has no upstream divergence: tight check of the kernel itself
     assert (outs["tail"][0][0] - outs["chain"][0][0]).abs().max().item() < 1e-4
     assert (outs["tail"][1][0] - outs["chain"][1][0]).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("Q", [1, 15, 16, 17, 64, 900, 1024, 1100])
+def test_sasa_kernels_all_sizes(Q):
+    """MFMA kernel (Q <= 1024) and the LDS-tiled VALU kernel (Q > 1024) against a float64 reference, with and
+    without the box table; ragged query counts around the 16-row tile."""
+    from racformer_amd.fused import box_prep, sasa_fused
+    rng = np.random.default_rng(Q)
+    H, d = 8, 32
+    qkv = torch.from_numpy(rng.standard_normal((1, Q, 3 * H * d), dtype=np.float32))
+    tau = torch.from_numpy(rng.random((1, Q, H), dtype=np.float32) * 2)
+    qb = torch.from_numpy(rng.random((1, Q, 10), dtype=np.float32))
+    q, k, v = (t_.view(1, Q, H, d).permute(0, 2, 1, 3).double() for t_ in qkv.split(H * d, dim=-1))
+    c = R.decode_bbox(R.theta_d2xy(qb), syn.PC_RANGE)[..., :2].double()
+    dist = -(c[:, :, None] - c[:, None]).norm(dim=-1)
+    logits = (q / np.sqrt(d)) @ k.transpose(-1, -2) + dist[:, None] * tau.double().permute(0, 2, 1)[..., None]
+    want = (torch.softmax(logits, -1) @ v).permute(0, 2, 1, 3).reshape(1, Q, H * d)
+    g = [x.to(DEV) for x in (qkv, tau, qb)]
+    for table in (None, box_prep(g[2], syn.PC_RANGE)):
+        got = sasa_fused(g[0], g[1], g[2], H, syn.PC_RANGE, box_table=table)
+        assert (got.cpu().double() - want).abs().max().item() < 5e-5, (Q, table is None)   # fp32 vs float64, logits O(10)

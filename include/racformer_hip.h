@@ -161,10 +161,16 @@ int rac_layer_tail_fwd(const void *const *acts, const void *const *weights, int 
  * Replaces the add / bias / split-K reduce + nn.LayerNorm (+ ReLU) (+ add) launch groups of the decoder layer
  * (models/racformer_transformer.py:170-177, 199-205, 243-258).  a: device f32, row r of partial s at
  * a + s*partial_stride + r*ld_a; residual / post_residual [rows][dim], bias [dim]: optional (NULL); out row r at
- * out + r*ld_out (so results can land in a column slice of a wider buffer); dim % 4 == 0, <= 1024. */
+ * out + r*ld_out (so results can land in a column slice of a wider buffer); dim % 4 == 0, <= 1024.
+ * split_out (optional, NULL to skip): device f16 [rows][3*dim + split_pad] = [hi | hi | lo | pad] with
+ * out*split_scale = hi + lo -- the K-concatenated A operand of a 3-product split GEMM (hi*Whi + hi*Wlo + lo*Whi,
+ * fp32 accumulate) on the f16 matrix cores, for the Linear layers that consume this row (split_scale: a power of
+ * two).  split_pad (0 or a multiple of 4) extra columns: the first two hold split_scale (the activation 1.0, which
+ * meets [bias_hi | bias_lo] in the weight image, so the GEMM adds the bias itself), the others 0. */
 int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, const float *residual,
                    const float *bias, const float *gamma, const float *beta, const float *post_residual,
-                   float *out, int ld_out, int rows, int dim, float eps, int relu, void *stream);
+                   float *out, int ld_out, int rows, int dim, float eps, int relu, void *split_out,
+                   float split_scale, int split_pad, void *stream);
 
 /* Position-encoder head  out = relu(LayerNorm(W x + b))  for the 3-wide box input
  * (models/racformer_transformer.py:170-173); x row r at x + r*ld_x (3 values), weight [256,3], out [rows,256]. */
@@ -179,15 +185,28 @@ int rac_pe_head_fwd(const float *x, int ld_x, const float *weight, const float *
 int rac_refine_fwd(const float *proposal, const float *delta, const float *time_diff_safe, float *bbox_pred,
                    float *bbox_xy, int B, int Q, int T, float num_ray, void *stream);
 
-/* AdaptiveMixing core on the matrix cores (exact-fp32 MFMA): per (query, group) item
+/* Matrix-core arithmetic of rac_mixing_fwd. */
+enum {
+    RAC_MIX_F32 = 0,   /* v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate (bit-for-bit an fmaf chain) */
+    RAC_MIX_F16X3 = 1  /* 16-bit matrix cores on split operands, f32 accumulate, fp32-GEMM accuracy: x @ M as three
+                          bf16 terms each (6 products, truncation 2^-23, any fp32 magnitude), S @ Y as two f16 terms
+                          each (3 products, truncation 2^-22; needs |S * param_scale| < 6e4) */
+};
+
+/* AdaptiveMixing core on the matrix cores: per (query, group) item
  *   Y = relu(LN_{[P,64]}(x @ M)),  Z = relu(LN_{[128,64]}(S @ Y))
  * Replaces the two batched matmuls, two layer norms and two ReLUs of AdaptiveMixing.inner_forward
  * (models/racformer_transformer.py:589-603); parameter_generator / out_proj remain library GEMMs.
  *   x      : device f32 [num_query, groups, in_points, 64]    (sampled features, B folded into num_query)
- *   params : device f32, row q at params + q*ld_params, per group [64*64 (M, in x out) | 128*in_points (S)]
- *   out    : device f32 [num_query, groups, 128, 64] */
-int rac_mixing_fwd(const float *x, const float *params, float *out, int ld_params, int num_query, int groups,
-                   int in_points, int channels, int out_points, float eps, void *stream);
+ *   params : device f32, row q at params + q*ld_params, per group [64*64 (M, in x out) | 128*in_points (S)];
+ *            every value is multiplied by param_scale on load (1.0, or the power-of-two alpha of a split GEMM)
+ *   out    : device f32 [num_query, groups, 128, 64] (NULL to skip when out_split is given)
+ *   out_split : optional device f16 [num_query, groups*8, 3, 1024]: every 1024-wide K slice of the flattened
+ *            output row as [hi | hi | lo] with out*split_scale = hi + lo -- the A operand of out_proj run as a
+ *            K-concatenated 3-product split GEMM on the f16 matrix cores (NULL to skip) */
+int rac_mixing_fwd(const float *x, const float *params, float param_scale, float *out, void *out_split,
+                   float split_scale, int ld_params, int num_query, int groups, int in_points, int channels, int out_points,
+                   float eps, int mfma_mode, void *stream);
 
 /* Backward of the two gather operators (SURVEY.md section 8 "next" row f4; fp32 features only).
  * rac_msmv_bwd  <- _ms_deform_attn_cuda_{c45,c2345,c23456}_backward, models/csrc/msmv_sampling/msmv_sampling.cpp:302-497

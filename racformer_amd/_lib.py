@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libracformer_hip.so")
 RAC_F32, RAC_BF16 = 0, 1
 OUT_SQCP, OUT_BQGTPC = 0, 1
+MIX_F32, MIX_F16X3 = 0, 1
 _lib = None
 
 # name -> (restype, argtypes); must list every symbol include/racformer_hip.h declares
@@ -29,10 +30,10 @@ SIGNATURES = {
     "rac_bev_pool_v2_fwd": (_i, [_vp] * 8 + [_i, _i, _vp]),
     "rac_bev_pool_v2_bwd": (_i, [_vp] * 10 + [_i, _i, _vp]),
     "rac_layer_tail_fwd": (_i, [_vp, _vp, _i, ctypes.c_int64] + [_i] * 5 + [_f, _f, _vp]),
-    "rac_add_ln_fwd": (_i, [_vp, _i, ctypes.c_int64, _i] + [_vp] * 6 + [_i, _i, _i, _f, _i, _vp]),
+    "rac_add_ln_fwd": (_i, [_vp, _i, ctypes.c_int64, _i] + [_vp] * 6 + [_i, _i, _i, _f, _i, _vp, _f, _i, _vp]),
     "rac_pe_head_fwd": (_i, [_vp, _i] + [_vp] * 5 + [_i, _i, _f, _vp]),
     "rac_refine_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_f, _vp]),
-    "rac_mixing_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_f, _vp]),
+    "rac_mixing_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _f] + [_i] * 6 + [_f, _i, _vp]),
     "rac_sasa_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
     "rac_bev_sampling_fwd": (_i, [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
 }

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
                                                      const float *__restrict__ residual, const float *__restrict__ bias,
                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                                      const float *__restrict__ post, float *__restrict__ out, int ld_out,
-                                                     int rows, int dim, float eps, int relu)
+                                                     int rows, int dim, float eps, int relu,
+                                                     _Float16 *__restrict__ split_out, float split_scale, int split_pad)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -79,6 +80,26 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
                 y.x += w.x; y.y += w.y; y.z += w.z; y.w += w.w;
             }
             *reinterpret_cast<rac_f4 *>(out + (size_t)row * ld_out + c * 4) = y;
+            if (split_out) {
+                // y * scale = hi + lo with hi, lo in f16 (22 significant bits together): the A operand of a
+                // 3-product split GEMM on the f16 matrix cores, written K-concatenated as [hi | hi | lo]
+                rac_h4 hi, lo;
+                rac_split_f16(y.x * split_scale, hi.x, lo.x);
+                rac_split_f16(y.y * split_scale, hi.y, lo.y);
+                rac_split_f16(y.z * split_scale, hi.z, lo.z);
+                rac_split_f16(y.w * split_scale, hi.w, lo.w);
+                _Float16 *dst = split_out + (size_t)row * (3 * dim + split_pad) + c * 4;
+                *reinterpret_cast<rac_h4 *>(dst) = hi;
+                *reinterpret_cast<rac_h4 *>(dst + dim) = hi;
+                *reinterpret_cast<rac_h4 *>(dst + 2 * dim) = lo;
+                if (split_pad && c == 0) {
+                    // bias columns of the K-concatenated GEMM: a constant activation 1.0 (scaled like the others)
+                    // against [bias_hi | bias_lo] rows of the weight image; the rest of the pad is zero
+                    _Float16 *pad = split_out + (size_t)row * (3 * dim + split_pad) + 3 * dim;
+                    for (int i = 0; i < split_pad; ++i)
+                        pad[i] = i < 2 ? (_Float16)split_scale : (_Float16)0.f;
+                }
+            }
         }
     }
 }
@@ -111,16 +132,19 @@ __global__ __launch_bounds__(256) void pe_head_kernel(const float *__restrict__ 
 
 extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, const float *residual,
                               const float *bias, const float *gamma, const float *beta, const float *post_residual,
-                              float *out, int ld_out, int rows, int dim, float eps, int relu, void *stream)
+                              float *out, int ld_out, int rows, int dim, float eps, int relu, void *split_out,
+                              float split_scale, int split_pad, void *stream)
 {
     RAC_CHECK_ARG(rows >= 0 && dim >= 4 && dim % 4 == 0 && dim <= 256 * ALN_MAX_V, "rac_add_ln_fwd: dim=%d (multiple of 4, <= %d)", dim, 256 * ALN_MAX_V);
     RAC_CHECK_ARG(num_partials >= 1, "rac_add_ln_fwd: num_partials=%d", num_partials);
+    RAC_CHECK_ARG(!split_out || split_pad == 0 || (split_pad >= 2 && split_pad % 4 == 0), "rac_add_ln_fwd: split_pad=%d (0, or a multiple of 4)", split_pad);
     RAC_CHECK_ARG(ld_a >= dim && ld_out >= dim && ld_a % 4 == 0 && ld_out % 4 == 0, "rac_add_ln_fwd: row strides ld_a=%d ld_out=%d", ld_a, ld_out);
     if (rows == 0)
         return 0;
     RAC_CHECK_ARG(a && gamma && beta && out, "rac_add_ln_fwd: null pointer");
     hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, num_partials,
-                       (long)partial_stride, ld_a, residual, bias, gamma, beta, post_residual, out, ld_out, rows, dim, eps, relu);
+                       (long)partial_stride, ld_a, residual, bias, gamma, beta, post_residual, out, ld_out, rows, dim, eps, relu,
+                       reinterpret_cast<_Float16 *>(split_out), split_scale, split_pad);
     return rac_launch_status("rac_add_ln_fwd");
 }
 

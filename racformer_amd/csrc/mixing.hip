@@ -31,9 +31,11 @@ typedef float mix_f4 __attribute__((ext_vector_type(4)));
 struct MixArgs {
     const float *x;       // [items_q, G, P, 64]
     const float *params;  // row q at params + q*ld_params: per group [64*64 | 128*P]
-    float *out;           // [items_q, G, 128, 64]
+    float *out;           // [items_q, G, 128, 64] (may be null when out_split is given)
+    _Float16 *out_split;  // optional: f16 [items_q, G*8, 3, 1024] = per 1024-wide K slice [hi | hi | lo] of out * split_scale
     int nq, G, P, ld_params;
-    float eps;
+    float eps, split_scale;
+    float param_scale;    // every generated parameter is multiplied by this on load (the split GEMM's power-of-two alpha)
 };
 
 __device__ __forceinline__ float mix_wave_sum(float v)
@@ -53,6 +55,35 @@ __device__ __forceinline__ float mix_block_sum(float v, float *red, int wave, in
         red[wave] = v;
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// copy the finished [128][64] tile from LDS to the fp32 output and / or the f16 split image
+__device__ __forceinline__ void mix_write_out(const MixArgs &a, const float *sO, int q, int g, int tid)
+{
+    if (a.out) {
+        float *go = a.out + ((size_t)q * a.G + g) * MIX_OUT * MIX_C;
+        for (int i = tid; i < MIX_OUT * MIX_C / 4; i += 256)
+            *reinterpret_cast<rac_f4 *>(go + i * 4) = *reinterpret_cast<const rac_f4 *>(sO + i * 4);
+    }
+    if (a.out_split) {
+        // A operand of out_proj as a 3-product split GEMM on the f16 matrix cores: the item's 8192 outputs are 8
+        // K-slices of 1024; slice s is stored as [hi(1024) | hi(1024) | lo(1024)] (K-concatenated products
+        // hi*Whi + hi*Wlo + lo*Whi), so the batched split-K GEMM reads it without any repacking.
+        _Float16 *go = a.out_split + ((size_t)q * a.G + g) * (MIX_OUT * MIX_C / 1024) * 3 * 1024;
+        for (int i = tid; i < MIX_OUT * MIX_C / 4; i += 256) {
+            const rac_f4 v = *reinterpret_cast<const rac_f4 *>(sO + i * 4);
+            rac_h4 hi, lo;
+            rac_split_f16(v.x * a.split_scale, hi.x, lo.x);
+            rac_split_f16(v.y * a.split_scale, hi.y, lo.y);
+            rac_split_f16(v.z * a.split_scale, hi.z, lo.z);
+            rac_split_f16(v.w * a.split_scale, hi.w, lo.w);
+            const int slice = i >> 8, kk = (i & 255) * 4;
+            _Float16 *dst = go + (size_t)slice * 3072 + kk;
+            *reinterpret_cast<rac_h4 *>(dst) = hi;
+            *reinterpret_cast<rac_h4 *>(dst + 1024) = hi;
+            *reinterpret_cast<rac_h4 *>(dst + 2048) = lo;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
@@ -100,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
                 if (c4 * 4 + 2 < P) v.z = src[2];
             }
         }
+        v.x *= a.param_scale; v.y *= a.param_scale; v.z *= a.param_scale; v.w *= a.param_scale;
         return v;
     };
     auto store_S = [&](int k, rac_f4 v) {
@@ -122,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
         for (int k = 0; k < 4; ++k) {          // M: 64 rows x 16 float4
             const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
             vm[k] = rac_ld4(gM + r * MIX_C + c4 * 4);
+            vm[k].x *= a.param_scale; vm[k].y *= a.param_scale; vm[k].z *= a.param_scale; vm[k].w *= a.param_scale;
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k)
@@ -242,14 +275,263 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_kernel(const MixArgs a)
         for (int r = 0; r < 4; ++r)
             sO[(16 * m + lk * 4 + r) * MIX_C + 16 * wave + li] = fmaxf((acc2[m][r] - mean2) * rstd2, 0.f);
     __syncthreads();
-    float *go = a.out + ((size_t)q * a.G + g) * MIX_OUT * MIX_C;
-    for (int i = tid; i < MIX_OUT * MIX_C / 4; i += 256)
-        *reinterpret_cast<rac_f4 *>(go + i * 4) = *reinterpret_cast<const rac_f4 *>(sO + i * 4);
+    mix_write_out(a, sO, q, g, tid);
 }
 
-extern "C" int rac_mixing_fwd(const float *x, const float *params, float *out, int ld_params, int num_query,
-                              int groups, int in_points, int channels, int out_points, float eps, void *stream)
+// ------------------------------------------------------------------------------------------------
+// Split-precision variant: the same two products on the 16-bit matrix cores (v_mfma_f32_16x16x32_{bf16,f16}) with
+// every operand split into 16-bit terms and the leading cross products accumulated in fp32 -- fp32-GEMM accuracy
+// at a fraction of the matrix-core time of the f32-input MFMA, which leaves the kernel bound by its 0.4 GB of
+// HBM traffic per launch.
+//   * x @ M: both operands as three bf16 terms (24 significant bits, fp32 exponent range: the sampled image
+//     features are data, nothing bounds them), the six products down to 2^-16 relative kept (truncation 2^-23);
+//   * S @ Y: two f16 terms each (22 bits), products hi*hi + hi*lo + lo*hi (truncation 2^-22).  Y is LayerNorm
+//     output (|Y| < 79); |S| is bounded by the caller from the generator's weights (AdaptiveMixing.split_packs);
+//   * x and S are converted once while being staged (LDS holds the 16-bit images, conflict-free row strides
+//     of 160 / 224 bytes for ds_read_b128 fragment reads);
+//   * wave w's slab of M (64 x 16) goes straight from global memory into B fragments (no LDS);
+//   * Y never leaves the registers: a 16x16 accumulator tile has its column on the lane and rows 4*lk..4*lk+3 in
+//     its 4 registers, so tiles (2t, 2t+1) ARE the B fragment of k-step t of the second product once converted,
+//     with k = 32t + 16h + 4lk + i  <->  fragment element 4h + i.  S is staged with that same k permutation
+//     (an 8-byte-granular shuffle inside each 32-wide block), so its A fragments stay single 16-byte reads.
+typedef _Float16 mix_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mix_b8 __attribute__((ext_vector_type(8)));
+struct alignas(8) mix_b4 {
+    __bf16 x, y, z, w;
+};
+// v = t1 + t2 + t3 exactly to 24 bits, each term a bf16 (round-to-nearest)
+__device__ __forceinline__ void mix_split_bf16(float v, __bf16 &t1, __bf16 &t2, __bf16 &t3)
 {
+    t1 = (__bf16)v;
+    const float r1 = v - (float)t1;
+    t2 = (__bf16)r1;
+    t3 = (__bf16)(r1 - (float)t2);
+}
+
+#define MIXH_XS 80    /* f16 row stride of the x images  (160 B) */
+#define MIXH_SS 112   /* f16 row stride of the S images  (224 B) */
+#define MIXH_X_BYTES (3 * MIX_PMAX * MIXH_XS * 2)   /* three bf16 terms: 46080 */
+#define MIXH_S_BYTES (2 * 64 * MIXH_SS * 2)         /* hi + lo of one 64-row half: 28672 */
+#define MIXH_LDS_BYTES (MIXH_X_BYTES + MIXH_S_BYTES + 64)
+
+__device__ __forceinline__ void mix_split4(const rac_f4 v, float scale, rac_h4 &hi, rac_h4 &lo)
+{
+    rac_split_f16(v.x * scale, hi.x, lo.x);
+    rac_split_f16(v.y * scale, hi.y, lo.y);
+    rac_split_f16(v.z * scale, hi.z, lo.z);
+    rac_split_f16(v.w * scale, hi.w, lo.w);
+}
+
+__global__ __launch_bounds__(256, 2) void mixing_c64_f16x3_kernel(const MixArgs a)
+{
+    extern __shared__ float smem[];
+    unsigned char *lds = reinterpret_cast<unsigned char *>(smem);
+    __bf16 *sX1 = reinterpret_cast<__bf16 *>(lds);                         // [96][80] x 3 terms
+    __bf16 *sX2 = sX1 + MIX_PMAX * MIXH_XS;
+    __bf16 *sX3 = sX2 + MIX_PMAX * MIXH_XS;
+    _Float16 *sS0h = reinterpret_cast<_Float16 *>(lds + MIXH_X_BYTES);     // [64][112]  S rows 0..63
+    _Float16 *sS0l = sS0h + 64 * MIXH_SS;
+    _Float16 *sS1h = reinterpret_cast<_Float16 *>(lds);                    // S rows 64..127 reuse the x region
+    _Float16 *sS1l = sS1h + 64 * MIXH_SS;
+    float *red = reinterpret_cast<float *>(lds + MIXH_X_BYTES + MIXH_S_BYTES);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int P = a.P;
+    const int item = blockIdx.x;
+    const int q = item / a.G, g = item % a.G;
+    const float *gx = a.x + ((size_t)q * a.G + g) * P * MIX_C;
+    const float *gM = a.params + (size_t)q * a.ld_params + (size_t)g * (MIX_C * MIX_C + MIX_OUT * P);
+    const float *gS = gM + MIX_C * MIX_C;
+    const float ps = a.param_scale;
+
+    // ---- all global loads of the item are issued up front (22 x 16 B + 16 x 4 B per thread) ------------------
+    const bool s_vec = (P & 3) == 0;
+    auto load_S = [&](int half, int k) -> rac_f4 {     // float4 number tid+256k of S rows 64*half.. (24 per row, zero-padded)
+        const int i = tid + 256 * k;
+        const int r = i / 24, c4 = i - r * 24;
+        const float *src = gS + (size_t)(64 * half + r) * P + c4 * 4;
+        rac_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c4 * 4 + 3 < P) {
+            if (s_vec) {
+                v = rac_ld4(src);
+            } else {
+                v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+            }
+        } else {
+            if (c4 * 4 + 0 < P) v.x = src[0];
+            if (c4 * 4 + 1 < P) v.y = src[1];
+            if (c4 * 4 + 2 < P) v.z = src[2];
+        }
+        return v;
+    };
+    auto store_S = [&](_Float16 *dh, _Float16 *dl, int k, const rac_f4 v) {
+        const int i = tid + 256 * k;
+        const int r = i / 24, c4 = i - r * 24;
+        // k = 4*c4 = 32t + 16h + 4lk'  ->  column 32t + 8lk' + 4h  (the accumulator-as-operand k order)
+        const int t = c4 >> 3, rem = c4 & 7, col = 32 * t + 8 * (rem & 3) + 4 * (rem >> 2);
+        rac_h4 hi, lo;
+        mix_split4(v, ps, hi, lo);
+        *reinterpret_cast<rac_h4 *>(dh + r * MIXH_SS + col) = hi;
+        *reinterpret_cast<rac_h4 *>(dl + r * MIXH_SS + col) = lo;
+    };
+    rac_f4 vx[6], vs0[6], vs1[6];
+    float mv[2][8];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
+        vx[k] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+        if (r < P)
+            vx[k] = rac_ld4(gx + r * MIX_C + c4 * 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            mv[ks][j] = gM[(32 * ks + 8 * lk + j) * MIX_C + 16 * wave + li];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        vs0[k] = load_S(0, k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        vs1[k] = load_S(1, k);
+
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
+        mix_b4 t1, t2, t3;                                                    // rows >= P are zeros
+        mix_split_bf16(vx[k].x, t1.x, t2.x, t3.x);
+        mix_split_bf16(vx[k].y, t1.y, t2.y, t3.y);
+        mix_split_bf16(vx[k].z, t1.z, t2.z, t3.z);
+        mix_split_bf16(vx[k].w, t1.w, t2.w, t3.w);
+        *reinterpret_cast<mix_b4 *>(sX1 + r * MIXH_XS + c4 * 4) = t1;
+        *reinterpret_cast<mix_b4 *>(sX2 + r * MIXH_XS + c4 * 4) = t2;
+        *reinterpret_cast<mix_b4 *>(sX3 + r * MIXH_XS + c4 * 4) = t3;
+    }
+    mix_b8 bM1[2], bM2[2], bM3[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 t1, t2, t3;
+            mix_split_bf16(mv[ks][j] * ps, t1, t2, t3);
+            bM1[ks][j] = t1;
+            bM2[ks][j] = t2;
+            bM3[ks][j] = t3;
+        }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        store_S(sS0h, sS0l, k, vs0[k]);
+    __syncthreads();
+
+    // ---- step 1: Y = x @ M, wave w -> columns 16w.. ------------------------------------------------------------
+    mix_f4 acc1[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        acc1[m] = (mix_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = (16 * m + li) * MIXH_XS + 32 * ks + 8 * lk;
+            const mix_b8 a1 = *reinterpret_cast<const mix_b8 *>(sX1 + off);
+            const mix_b8 a2 = *reinterpret_cast<const mix_b8 *>(sX2 + off);
+            const mix_b8 a3 = *reinterpret_cast<const mix_b8 *>(sX3 + off);
+            // smallest terms first
+            acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, bM1[ks], acc1[m], 0, 0, 0);
+            acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bM2[ks], acc1[m], 0, 0, 0);
+            acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bM3[ks], acc1[m], 0, 0, 0);
+            acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bM1[ks], acc1[m], 0, 0, 0);
+            acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bM2[ks], acc1[m], 0, 0, 0);
+            acc1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bM1[ks], acc1[m], 0, 0, 0);
+        }
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            part += (16 * m + lk * 4 + r < P) ? acc1[m][r] : 0.f;
+    const float n1 = (float)(P * MIX_C);
+    const float mean1 = mix_block_sum(part, red, wave, lane) / n1;
+    part = 0.f;
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = acc1[m][r] - mean1;
+            part += (16 * m + lk * 4 + r < P) ? d * d : 0.f;
+        }
+    const float rstd1 = 1.f / sqrtf(mix_block_sum(part, red, wave, lane) / n1 + a.eps);
+    // (both block sums end with barriers: every wave is past its last read of the x images, so the region can
+    //  take S rows 64..127 now)
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        store_S(sS1h, sS1l, k, vs1[k]);
+    // Y = relu(LN(.)) -> B fragments of the second product, in registers
+    mix_h8 bYh[3], bYl[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 2 * t + h, row = 16 * m + lk * 4 + r;
+                const float y = row < P ? fmaxf((acc1[m][r] - mean1) * rstd1, 0.f) : 0.f;
+                _Float16 yh, yl;
+                rac_split_f16(y, yh, yl);
+                bYh[t][4 * h + r] = yh;
+                bYl[t][4 * h + r] = yl;
+            }
+    __syncthreads();   // S rows 64..127 visible
+
+    // ---- step 2: Z = S @ Y ---------------------------------------------------------------------------------------
+    mix_f4 acc2[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        acc2[m] = (mix_f4){0.f, 0.f, 0.f, 0.f};
+        const _Float16 *sh = m < 4 ? sS0h : sS1h, *sl = m < 4 ? sS0l : sS1l;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int off = (16 * (m & 3) + li) * MIXH_SS + 32 * t + 8 * lk;
+            const mix_h8 ah = *reinterpret_cast<const mix_h8 *>(sh + off);
+            const mix_h8 al = *reinterpret_cast<const mix_h8 *>(sl + off);
+            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bYh[t], acc2[m], 0, 0, 0);
+            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bYl[t], acc2[m], 0, 0, 0);
+            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bYh[t], acc2[m], 0, 0, 0);
+        }
+    }
+    part = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            part += acc2[m][r];
+    const float n2 = (float)(MIX_OUT * MIX_C);
+    const float mean2 = mix_block_sum(part, red, wave, lane) / n2;
+    part = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = acc2[m][r] - mean2;
+            part += d * d;
+        }
+    const float rstd2 = 1.f / sqrtf(mix_block_sum(part, red, wave, lane) / n2 + a.eps);
+    // every wave is past its S reads: stage the normalised [128][64] tile (32 KB) over the x / S images
+    float *sO = smem;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            sO[(16 * m + lk * 4 + r) * MIX_C + 16 * wave + li] = fmaxf((acc2[m][r] - mean2) * rstd2, 0.f);
+    __syncthreads();
+    mix_write_out(a, sO, q, g, tid);
+}
+
+extern "C" int rac_mixing_fwd(const float *x, const float *params, float param_scale, float *out, void *out_split,
+                              float split_scale, int ld_params, int num_query, int groups, int in_points, int channels, int out_points,
+                              float eps, int mfma_mode, void *stream)
+{
+    RAC_CHECK_ARG(mfma_mode == RAC_MIX_F32 || mfma_mode == RAC_MIX_F16X3, "rac_mixing_fwd: mfma_mode=%d", mfma_mode);
     RAC_CHECK_ARG(channels == MIX_C && out_points == MIX_OUT,
                   "rac_mixing_fwd: built for 64 channels per group and 128 out points (got %d, %d)", channels, out_points);
     RAC_CHECK_ARG(in_points >= 1 && in_points <= MIX_PMAX, "rac_mixing_fwd: in_points=%d out of [1,%d]", in_points, MIX_PMAX);
@@ -261,15 +543,28 @@ extern "C" int rac_mixing_fwd(const float *x, const float *params, float *out, i
     static_assert(MIX_REGION_A >= MIX_PMAX * MIX_MS, "Y must fit region A");
     if (num_query == 0)
         return 0;
-    RAC_CHECK_ARG(x && params && out, "rac_mixing_fwd: null pointer");
+    RAC_CHECK_ARG(x && params && (out || out_split), "rac_mixing_fwd: null pointer");
     MixArgs a;
     a.x = x; a.params = params; a.out = out;
+    a.out_split = reinterpret_cast<_Float16 *>(out_split); a.split_scale = split_scale; a.param_scale = param_scale;
     a.nq = num_query; a.G = groups; a.P = in_points; a.ld_params = ld_params; a.eps = eps;
     const size_t lds = (size_t)MIX_LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mixing_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
+    }
+    if (mfma_mode == RAC_MIX_F16X3) {
+        static_assert(MIXH_X_BYTES >= MIXH_S_BYTES, "S rows 64..127 reuse the x region");
+        static_assert(2 * MIXH_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+        static_assert(MIXH_X_BYTES + MIXH_S_BYTES >= MIX_OUT * MIX_C * 4, "output tile must fit the x | S region");
+        static bool attr16_set = false;
+        if (!attr16_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mixing_c64_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MIXH_LDS_BYTES);
+            attr16_set = true;
+        }
+        hipLaunchKernelGGL(mixing_c64_f16x3_kernel, dim3(num_query * groups), dim3(256), MIXH_LDS_BYTES, (hipStream_t)stream, a);
+        return rac_launch_status("rac_mixing_fwd");
     }
     hipLaunchKernelGGL(mixing_c64_kernel, dim3(num_query * groups), dim3(256), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_mixing_fwd");

@@ -52,3 +52,14 @@ __device__ __forceinline__ rac_f4 rac_ld4(const unsigned short *p)
     o.w = __uint_as_float(r.y & 0xffff0000u);
     return o;
 }
+
+// f32 = hi + lo, both f16 (round-to-nearest): hi carries 11 significant bits, lo the next 11.
+struct alignas(8) rac_h4 {
+    _Float16 x, y, z, w;
+};
+
+__device__ __forceinline__ void rac_split_f16(float v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}

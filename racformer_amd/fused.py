@@ -140,21 +140,30 @@ def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range, box_table=None):
     return out
 
 
-def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5):
+def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5, split=False, param_scale=1.0, f16x3=False):
     """x [B,Q,G,P,64] (contiguous), params [B,Q,G*(64*64+128*P)] (unit inner stride) ->
-    relu(LN(S @ relu(LN(x @ M)))) as [B,Q,G*128*64], ready for out_proj."""
+    relu(LN(S @ relu(LN(x @ M)))) as [B,Q,G*128*64], ready for out_proj.
+    ``split=True``: instead returns the f16 image [B*Q, G*8, 3072] of the same values * SPLIT_ACT_SCALE, every
+    1024-wide K slice stored as [hi | hi | lo] (A operand of the split-K split-precision out_proj GEMM).
+    ``param_scale``: factor applied to every parameter on load (the power-of-two alpha of a split generator GEMM).
+    ``f16x3``: run the two products as 3-product split-precision f16 MFMAs (RAC_MIX_F16X3) instead of f32-input MFMAs."""
     _lib.require_gpu(x, what="mixing_fused")
     B, Q, G, P, C = x.shape
     if G != n_groups or P != in_points or x.dtype != torch.float32:
         raise RuntimeError("mixing_fused: x must be float32 [B,Q,G,P,64]")
     width = G * (C * C + out_points * P)
     p_par, ld_par = _rows(params, width, "mixing_fused(params)")
-    out = torch.empty(B, Q, G * out_points * C, device=x.device, dtype=torch.float32)
+    if split:
+        out = torch.empty(B * Q, G * out_points * C // 1024, 3 * 1024, device=x.device, dtype=torch.float16)
+    else:
+        out = torch.empty(B, Q, G * out_points * C, device=x.device, dtype=torch.float32)
     ev = _lib.timer.record("mixing_fwd") if _lib.timer is not None else None
     if ev:
         ev[0].record()
-    rc = _lib.lib().rac_mixing_fwd(_lib.ptr(x), p_par, _lib.ptr(out), ld_par, B * Q, G, P, C, out_points, float(eps),
-                                   _lib.stream_ptr())
+    rc = _lib.lib().rac_mixing_fwd(_lib.ptr(x), p_par, float(param_scale), None if split else _lib.ptr(out),
+                                   _lib.ptr(out) if split else None,
+                                   SPLIT_ACT_SCALE, ld_par, B * Q, G, P, C, out_points, float(eps),
+                                   _lib.MIX_F16X3 if f16x3 else _lib.MIX_F32, _lib.stream_ptr())
     if ev:
         ev[1].record()
     _lib.check(rc, "rac_mixing_fwd")
@@ -174,10 +183,16 @@ def refine_fused(proposal, delta, time_diff_safe, num_ray):
     return pred, xy
 
 
-def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=None, out=None):
+SPLIT_ACT_SCALE = 16.0   # power of two applied to activations before the f16 hi/lo split (keeps lo out of f16 subnormals)
+SPLIT_BIAS_PAD = 8       # extra K columns of a split image that carry the bias ([1, 1, 0...] against [b_hi, b_lo, 0...])
+
+
+def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=None, out=None, split=False):
     """[relu](LayerNorm(sum_s a[s] + residual + bias)) [+ post] with ``norm`` an nn.LayerNorm; a is [..., dim]
     (unit inner stride; rows may be a column slice of a wider tensor) or [S, ..., dim] with num_partials=S.
-    ``out``: optional destination (may itself be a column slice).  One launch."""
+    ``out``: optional destination (may itself be a column slice).  One launch.
+    ``split=True``: also returns the f16 [rows, 3*dim + SPLIT_BIAS_PAD] = [hi | hi | lo | 1 1 0..] image of
+    ``out * SPLIT_ACT_SCALE`` (A operand of a split GEMM, see ``split_weight_f16``)."""
     _lib.require_gpu(norm.weight, what="add_ln")
     dim = a.shape[-1]
     if num_partials > 1:
@@ -204,13 +219,43 @@ def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=N
         if out.stride(-1) != 1 or out.shape[-1] != dim:
             raise RuntimeError("add_ln: out must have unit inner stride and the normalised width")
         ld_out = out.stride(-2)
+    split_out = torch.empty(rows, 3 * dim + SPLIT_BIAS_PAD, device=a.device, dtype=torch.float16) if split else None
     rc = _lib.lib().rac_add_ln_fwd(_lib.ptr(a), num_partials, rows * dim, ld_a,
                                    _lib.ptr(residual) if residual is not None else None,
                                    _lib.ptr(bias) if bias is not None else None, _lib.ptr(norm.weight), _lib.ptr(norm.bias),
                                    _lib.ptr(post) if post is not None else None, _lib.ptr(out), ld_out, rows, dim,
-                                   float(norm.eps), int(relu), _lib.stream_ptr())
+                                   float(norm.eps), int(relu), _lib.ptr(split_out) if split else None,
+                                   SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, _lib.stream_ptr())
     _lib.check(rc, "rac_add_ln_fwd")
-    return out
+    return (out, split_out) if split else out
+
+
+def split_weight_f16(weight, bias=None):
+    """nn.Linear weight [N,K] fp32 -> (f16 [N,3K] = [hi | lo | hi] of weight * 2^s, alpha) such that
+        x @ weight.T  ==  alpha * ([x_hi | x_hi | x_lo] @ [w_hi | w_lo | w_hi].T)        (x * SPLIT_ACT_SCALE = x_hi + x_lo)
+    up to the dropped lo*lo term (2^-22 relative): fp32-GEMM accuracy from three f16 MFMA products accumulated in
+    fp32.  2^s brings max|w| to [2^13, 2^14) so that the lo parts stay clear of f16 subnormals; alpha undoes both
+    power-of-two scalings exactly.  With ``bias`` the image is [N, 3K + SPLIT_BIAS_PAD] = [.. | b_hi | b_lo | 0..]
+    (bias * 2^s): against the [.. | 1 | 1 | 0..] columns of add_ln's activation image the GEMM adds the bias
+    itself.  Done once per set of weights (the caller caches it).  (None, None) if f16 cannot hold the operands."""
+    import math
+    w = weight.detach().float()
+    amax = float(w.abs().max())
+    if not (amax > 0.0) or amax != amax or amax == float("inf"):
+        return None, None
+    s = 13 - math.frexp(amax)[1] + 1          # amax * 2^s in [2^13, 2^14)
+    ws = w * (2.0 ** s)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    parts = [hi, lo, hi]
+    if bias is not None:
+        bs = bias.detach().float() * (2.0 ** s)
+        if not float(bs.abs().max()) < 6.0e4:
+            return None, None
+        bh = bs.to(torch.float16)
+        bl = (bs - bh.float()).to(torch.float16)
+        parts += [bh[:, None], bl[:, None], hi.new_zeros(hi.shape[0], SPLIT_BIAS_PAD - 2)]
+    return torch.cat(parts, dim=1).contiguous(), 2.0 ** (-s) / SPLIT_ACT_SCALE
 
 
 def pe_head(x3, linear, norm):

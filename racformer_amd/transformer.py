@@ -25,7 +25,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import LayerTailWeights, add_ln, bev_sampling_fused, layer_tail_fused, pe_head, box_prep, mixing_fused, refine_fused, sampling4d_fused, sasa_fused
+from .fused import (SPLIT_ACT_SCALE, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
+                    pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -494,26 +495,75 @@ class AdaptiveMixing(nn.Module):
         B, Q, G, P, C = x.shape
         return x.is_cuda and C == 64 and self.eff_out_dim == 64 and self.out_points == 128 and P <= 96
 
-    def out_proj_partials(self, x, query, out_proj_split, params=None):
+    # The two big Linears of the mixing (30 + 15 GFLOP per layer) on the f16 matrix cores at fp32-GEMM accuracy:
+    # every operand is split as v = hi + lo (two f16, 22 significant bits) and the three leading products
+    # hi*Whi + hi*Wlo + lo*Whi are accumulated in fp32 by ONE library GEMM over the K-concatenated operands
+    # ([hi | hi | lo] x [Whi | Wlo | Whi]); measured error vs float64 equals the fp32 GEMM's (tools/exp_splitgemm.py)
+    # at 2.3x the fp32-MFMA GEMM rate.  Power-of-two scalings keep the lo parts out of f16 subnormals and are
+    # undone exactly by the GEMM's alpha.
+    SPLIT_SLICE = 1024   # K slice of out_proj's split-K batches; fixed by rac_mixing_fwd's out_split layout
+
+    def split_packs(self, act_bound=None):
+        """-> dict(gen_w [N,3K+8] f16, gen_alpha, out_w [S,256,3*1024] f16, out_alpha), or {} if f16 cannot hold the
+        operands: a weight or bias overflows, |activation| bound * SPLIT_ACT_SCALE >= 6e4, or the generated
+        parameters -- bounded by max_row ||W_row||_1 * act_bound + max|bias| -- could reach the f16 range that
+        rac_mixing_fwd's RAC_MIX_F16X3 mode needs for S.  (One-off host reads; the result is cached.)"""
+        gen = self.parameter_generator
+        w = self.out_proj.weight
+        N, K = w.shape
+        if K % self.SPLIT_SLICE != 0:
+            return {}
+        if act_bound is not None:
+            param_bound = float(gen.weight.detach().abs().sum(dim=1).max()) * act_bound + float(gen.bias.detach().abs().max())
+            if not (act_bound * SPLIT_ACT_SCALE < 6.0e4 and param_bound < 6.0e4):
+                return {}
+        gen_w, gen_alpha = split_weight_f16(gen.weight, gen.bias)
+        if gen_w is None:
+            return {}
+        S = K // self.SPLIT_SLICE
+        ow, out_alpha = split_weight_f16(w.detach().view(N, S, self.SPLIT_SLICE).permute(1, 0, 2).reshape(S * N, self.SPLIT_SLICE))
+        if ow is None:
+            return {}
+        return dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow.view(S, N, 3 * self.SPLIT_SLICE), out_alpha=out_alpha)
+
+    def out_proj_partials(self, x, query, out_proj_split, params=None, packs=None, query_split=None):
         """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
         out_proj.  Returns the S partial products [S, B*Q, query_dim]; their sum + out_proj.bias + query
         is inner_forward's result (the caller folds that sum into its LayerNorm kernel).  ``params``:
-        the generator output if the caller already produced it (on a side stream)."""
+        the generator output if the caller already produced it (on a side stream).  ``packs`` +
+        ``query_split`` ([B*Q, 3*query_dim] f16 from add_ln(split=True)): both GEMMs as split-precision
+        f16-MFMA GEMMs (see split_packs)."""
         B, Q, G, P, C = x.shape
         timer = _lib.timer
+        split = bool(packs) and query_split is not None
+        params_scaled = False
         if params is None:
             ev = timer.record("mixing_generator_gemm") if timer is not None else None
             if ev:
                 ev[0].record()
-            params = self.parameter_generator(query)
+            if split:
+                # bias rides in the K-concatenated operands; alpha (a power of two) is applied by the mixing kernel
+                params = torch.mm(query_split, packs["gen_w"].t(), out_dtype=torch.float32).view(B, Q, -1)
+                params_scaled = True
+            else:
+                params = self.parameter_generator(query)
             if ev:
                 ev[1].record()
-        out = mixing_fused(x.contiguous(), params, P, G, self.out_points)
-        S_, N, k = out_proj_split.shape
+        out = mixing_fused(x.contiguous(), params, P, G, self.out_points, split=split,
+                           param_scale=packs["gen_alpha"] if split and params_scaled else 1.0, f16x3=split)
         ev = timer.record("mixing_out_proj_gemm") if timer is not None else None
         if ev:
             ev[0].record()
-        partials = torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
+        if split:
+            ow = packs["out_w"]                                            # [S, N, 3k]
+            zero = packs.get("zero")
+            if zero is None or zero.shape[1] != B * Q:
+                zero = packs["zero"] = torch.zeros(ow.shape[0], B * Q, ow.shape[1], device=x.device, dtype=torch.float32)
+            partials = torch.baddbmm(zero, out.transpose(0, 1), ow.transpose(1, 2), beta=0, alpha=packs["out_alpha"],
+                                     out_dtype=torch.float32)
+        else:
+            S_, N, k = out_proj_split.shape
+            partials = torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
         if ev:
             ev[1].record()
         return partials
@@ -599,6 +649,20 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # (memory-bound).  Measured: no gain on MI355X (92.9 vs 92.7 samples/s) -- the GEMM's workgroups occupy every
         # CU, the kernels do not co-schedule -- so it stays off.
         self.overlap = False
+        # The mixing generator and out_proj as split-precision f16-MFMA GEMMs (AdaptiveMixing.split_packs).  False: fp32 rocBLAS.
+        self.split_gemm = True
+        self._pack_cache = {}
+
+    def _cached(self, key, params, fn):
+        """Weight-derived operands (concatenations, re-layouts, f16 splits) are functions of the parameters only:
+        built at the first forward and reused until a parameter is replaced or modified in place."""
+        sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        hit = self._pack_cache.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, fn())
+            self._pack_cache[key] = hit
+        return hit[1]
 
     @torch.no_grad()
     def init_weights(self):
@@ -636,16 +700,30 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         """Layer-invariant tensors (computed once per forward)."""
         radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats)
         lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
-        w, b, widths = self._wide_linears()
+        rb, lb, mix = self.sampling_radar_bev, self.sampling_lss_bev, self.mixing
+        wide_mods = [self.sampling.sampling_offset, self.sampling.ray_points_offset, self.sampling.scale_weights]
+        for x in (rb, lb):
+            wide_mods += [x.sampling_offset, x.ray_points_offset, x.scale_weights, x.attention.bev_queue_weight]
+        w, b, widths = self._cached("wide", [p for m in wide_mods for p in (m.weight, m.bias)], self._wide_linears)
+        ro, lo = rb.attention.output_proj, lb.attention.output_proj
+        bev_owt, bev_ob = self._cached("bev_o", [ro.weight, lo.weight, ro.bias, lo.bias], lambda: (
+            torch.stack([ro.weight.t(), lo.weight.t()]).contiguous(), torch.stack([ro.bias, lo.bias])[:, None, :].contiguous()))
+        c0, r0 = self.cls_branch[0], self.reg_branch[0]
+        c0r0_w, c0r0_b = self._cached("c0r0", [c0.weight, r0.weight, c0.bias, r0.bias], lambda: (
+            torch.cat([c0.weight, r0.weight], dim=0), torch.cat([c0.bias, r0.bias], dim=0)))
+        at = self.self_attn
+        sasa_w = self._cached("sasa", [at.attention.attn.in_proj_weight, at.gen_tau.weight, at.attention.attn.in_proj_bias,
+                                       at.gen_tau.bias], at.wide_in_proj)
+        packs = {}
+        if self.split_gemm and radar_value.is_cuda and self.fused:
+            # |norm1 output| <= sqrt(E) * max|gamma| + max|beta| bounds the generator's A operand
+            packs = self._cached("split_packs", [mix.parameter_generator.weight, mix.parameter_generator.bias,
+                                                 mix.out_proj.weight, self.norm1.weight, self.norm1.bias], lambda: mix.split_packs(
+                float(self.norm1.weight.abs().max()) * math.sqrt(self.embed_dims) + float(self.norm1.bias.abs().max())))
+        out_proj_split = None if packs else self._cached("out_proj_split", [mix.out_proj.weight], mix.split_out_proj)
         return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
-                    wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=self.mixing.split_out_proj(),
-                    sasa_w=self.self_attn.wide_in_proj(),
-                    bev_owt=torch.stack([self.sampling_radar_bev.attention.output_proj.weight.t(),
-                                         self.sampling_lss_bev.attention.output_proj.weight.t()]).contiguous(),
-                    bev_ob=torch.stack([self.sampling_radar_bev.attention.output_proj.bias,
-                                        self.sampling_lss_bev.attention.output_proj.bias])[:, None, :].contiguous(),
-                    c0r0_w=torch.cat([self.cls_branch[0].weight, self.reg_branch[0].weight], dim=0),
-                    c0r0_b=torch.cat([self.cls_branch[0].bias, self.reg_branch[0].bias], dim=0),
+                    wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=out_proj_split, split_packs=packs,
+                    sasa_w=sasa_w, bev_owt=bev_owt, bev_ob=bev_ob, c0r0_w=c0r0_w, c0r0_b=c0r0_b,
                     **({"side_stream": self._side_stream(radar_value.device)} if radar_value.is_cuda else {}),
                     **({"tail": LayerTailWeights(self)} if self.fused and self.tail_kernel and radar_value.is_cuda
                        and self.embed_dims == 256 and self.code_size == 10 and self.num_classes <= 16 else {}))
@@ -667,7 +745,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         lin = F.linear(x, prepared["sasa_w"][0], prepared["sasa_w"][1])
         attn = p.out_proj(sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], qb, self.self_attn.num_heads, self.pc_range,
                                      box_table=table))
-        x1 = add_ln(attn, self.norm1, residual=x)
+        packs = prepared.get("split_packs")
+        x1, x1_split = add_ln(attn, self.norm1, residual=x, split=True) if packs else (add_ln(attn, self.norm1, residual=x), None)
         # The 30-GFLOP parameter generator of AdaptiveMixing needs only x1.  It is MFMA-bound while the three
         # sampling kernels are memory / L2-bound, so it runs on a second HIP stream beside them.
         params = None
@@ -700,7 +779,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # adaptive mixing: generator GEMM -> MFMA kernel -> split-K partial products of out_proj
         if side is not None:
             torch.cuda.current_stream().wait_event(done)
-        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], params)
+        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], params, packs, x1_split)
         if stages is None and self.tail_kernel and "tail" in prepared:
             # everything that remains of the layer in one launch (rac_layer_tail_fwd)
             x3, cls_score, bbox_pred, bbox_xy = layer_tail_fused(prepared["tail"], x1, bev[0], bev[1], partials, qb,

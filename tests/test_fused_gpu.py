@@ -106,9 +106,19 @@ def test_mixing_fused(P):
         mg = mix.to(DEV)
         got = mg(x.to(DEV), q.to(DEV), mg.split_out_proj())
         unf = mg(x.to(DEV), q.to(DEV))
+        # the two arithmetic modes of the kernel itself on identical parameters (large-magnitude features included:
+        # the x operand of RAC_MIX_F16X3 is split into bf16 terms, so it keeps the fp32 exponent range)
+        from racformer_amd.fused import mixing_fused
+        xs = x.to(DEV) * torch.tensor([1.0, 3.0e5, 1.0e-6, 40.0], device=DEV).view(1, 1, 4, 1, 1)
+        params = mg.parameter_generator(q.to(DEV))
+        z32 = mixing_fused(xs, params, P, 4, 128)
+        z16 = mixing_fused(xs, params, P, 4, 128, f16x3=True)
+        zs = mixing_fused(xs, params * 4.0, P, 4, 128, f16x3=True, param_scale=0.25)
     torch.cuda.synchronize()
     assert (got - unf).abs().max().item() < 2e-4
     assert (got.cpu() - ref).abs().max().item() < 2e-4
+    assert torch.isfinite(z16).all() and (z16 - z32).abs().max().item() < 5e-5, (z16 - z32).abs().max().item()
+    assert torch.equal(zs, z16)          # power-of-two parameter scale is exact
 
 
 def test_refine_and_add_ln_kernels():
@@ -188,3 +198,70 @@ def test_sasa_kernels_all_sizes(Q):
     for table in (None, box_prep(g[2], syn.PC_RANGE)):
         got = sasa_fused(g[0], g[1], g[2], H, syn.PC_RANGE, box_table=table)
         assert (got.cpu().double() - want).abs().max().item() < 5e-5, (Q, table is None)   # fp32 vs float64, logits O(10)
+
+
+def test_split_precision_operands_and_gemms():
+    """The f16 hi/lo images written by rac_add_ln_fwd / rac_mixing_fwd reproduce the fp32 values to 2^-21, and the
+    K-concatenated 3-product GEMMs built on them match a float64 GEMM as closely as the fp32 GEMM does."""
+    from racformer_amd.fused import SPLIT_ACT_SCALE, add_ln, mixing_fused, split_weight_f16
+    from racformer_amd.transformer import AdaptiveMixing
+    torch.manual_seed(5)
+    ln = torch.nn.LayerNorm(256).to(DEV)
+    a, res = torch.randn(1, 900, 256, device=DEV), torch.randn(1, 900, 256, device=DEV)
+    out, img = add_ln(a, ln, residual=res, split=True)
+    assert img.dtype == torch.float16 and tuple(img.shape) == (900, 776)
+    hi, hi2, lo, pad = img.float().split([256, 256, 256, 8], dim=1)
+    assert torch.equal(pad, torch.tensor([SPLIT_ACT_SCALE] * 2 + [0.0] * 6, device=DEV).expand(900, 8))
+    assert torch.equal(hi, hi2)
+    rec = (hi.double() + lo.double()) / SPLIT_ACT_SCALE
+    assert (rec - out.view(900, 256).double()).abs().max().item() <= 2.0 ** -21 * out.abs().max().item()
+    # generator-shaped GEMM: split path vs fp32 rocBLAS vs float64
+    lin = torch.nn.Linear(256, 4096).to(DEV)
+    w3, alpha = split_weight_f16(lin.weight, lin.bias)
+    got = torch.mm(img, w3.t(), out_dtype=torch.float32) * alpha
+    want = out.view(900, 256).double() @ lin.weight.double().t() + lin.bias.double()
+    e_split = (got.double() - want).abs().max().item()
+    e_fp32 = (lin(out.view(900, 256)).double() - want).abs().max().item()
+    assert e_split < 4 * e_fp32 + 1e-6, (e_split, e_fp32)
+    # mixing kernel: split image of the output vs its fp32 output; then out_proj both ways
+    mix = AdaptiveMixing(in_dim=256, in_points=96, n_groups=4, out_points=128).eval().to(DEV)
+    x, q = torch.randn(1, 64, 4, 96, 64, device=DEV), torch.randn(1, 64, 256, device=DEV)
+    with torch.no_grad():
+        params = mix.parameter_generator(q)
+        z = mixing_fused(x, params, 96, 4, 128)
+        z16 = mixing_fused(x, params, 96, 4, 128, split=True)
+        assert tuple(z16.shape) == (64, 32, 3072)
+        zh, zh2, zl = z16.float().view(64, 32, 3, 1024).unbind(2)
+        assert torch.equal(zh, zh2)
+        rec = ((zh.double() + zl.double()) / SPLIT_ACT_SCALE).reshape(64, -1)
+        assert (rec - z.view(64, -1).double()).abs().max().item() <= 2.0 ** -21 * z.abs().max().item()
+        packs = mix.split_packs()
+        part = torch.baddbmm(torch.zeros(32, 64, 256, device=DEV), z16.transpose(0, 1), packs["out_w"].transpose(1, 2),
+                             beta=0, alpha=packs["out_alpha"], out_dtype=torch.float32)
+        want = z.view(64, -1).double() @ mix.out_proj.weight.double().t()
+        e_split = (part.sum(0).double() - want).abs().max().item()
+        e_fp32 = ((z.view(64, -1) @ mix.out_proj.weight.t()).double() - want).abs().max().item()
+        assert e_split < 4 * e_fp32 + 1e-6, (e_split, e_fp32)
+    assert mix.split_packs(act_bound=1e5) == {}     # operands outside the f16 range: the caller keeps the fp32 GEMMs
+
+
+@pytest.mark.parametrize("cfg", [syn.SMALL6, syn.F8])
+def test_split_gemm_decoder_matches_fp32_gemm_decoder(cfg):
+    """Whole decoder with the mixing Linears as split-precision f16-MFMA GEMMs (default) vs as fp32 rocBLAS GEMMs."""
+    outs = {}
+    for split in (True, False):
+        tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+        syn.fill_params(tr, 62)
+        tr.decoder.decoder_layer.split_gemm = split
+        tr = tr.to(DEV)
+        qb, qf = syn.make_queries(cfg, 61)
+        with torch.no_grad():
+            outs[split] = tr(qb.to(DEV), qf.to(DEV), [f.to(DEV) for f in syn.make_pyramid(cfg, 61)],
+                             syn.make_bev(cfg, 61, 0).to(DEV), syn.make_bev(cfg, 61, 1).to(DEV), None,
+                             syn.make_img_metas(cfg))
+        cache = tr.decoder.decoder_layer._pack_cache
+        assert (bool(cache["split_packs"][1]) if split else "split_packs" not in cache)
+    torch.cuda.synchronize()
+    from parity import decoder_parity
+    decoder_parity(outs[True][0], outs[True][1], outs[False][0].cpu(), outs[False][1].cpu(), what="split vs fp32 GEMMs")
+    assert (outs[True][1][0] - outs[False][1][0]).abs().max().item() < 1e-4     # layer 0: no upstream divergence

@@ -157,7 +157,7 @@ int rac_layer_tail_fwd(const void *const *acts, const void *const *weights, int 
                        int64_t partial_stride, int B, int Q, int T, int num_classes, int code_size,
                        float num_ray, float eps, void *stream);
 
-/* Row-wise  out = [relu]( LayerNorm( sum_{s<num_partials} a[s] + residual + bias ) * gamma + beta ) [+ post_residual].
+/* Row-wise  out = [relu]( LayerNorm( a_scale * sum_{s<num_partials} a[s] + residual + bias ) * gamma + beta ) [+ post_residual].
  * Replaces the add / bias / split-K reduce + nn.LayerNorm (+ ReLU) (+ add) launch groups of the decoder layer
  * (models/racformer_transformer.py:170-177, 199-205, 243-258).  a: device f32, row r of partial s at
  * a + s*partial_stride + r*ld_a; residual / post_residual [rows][dim], bias [dim]: optional (NULL); out row r at
@@ -167,7 +167,7 @@ int rac_layer_tail_fwd(const void *const *acts, const void *const *weights, int 
  * fp32 accumulate) on the f16 matrix cores, for the Linear layers that consume this row (split_scale: a power of
  * two).  split_pad (0 or a multiple of 4) extra columns: the first two hold split_scale (the activation 1.0, which
  * meets [bias_hi | bias_lo] in the weight image, so the GEMM adds the bias itself), the others 0. */
-int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, const float *residual,
+int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, float a_scale, const float *residual,
                    const float *bias, const float *gamma, const float *beta, const float *post_residual,
                    float *out, int ld_out, int rows, int dim, float eps, int relu, void *split_out,
                    float split_scale, int split_pad, void *stream);
@@ -201,7 +201,7 @@ enum {
  *   params : device f32, row q at params + q*ld_params, per group [64*64 (M, in x out) | 128*in_points (S)];
  *            every value is multiplied by param_scale on load (1.0, or the power-of-two alpha of a split GEMM)
  *   out    : device f32 [num_query, groups, 128, 64] (NULL to skip when out_split is given)
- *   out_split : optional device f16 [num_query, groups*8, 3, 1024]: every 1024-wide K slice of the flattened
+ *   out_split : optional device f16 [num_query, groups*4, 3, 2048]: every 2048-wide K slice of the flattened
  *            output row as [hi | hi | lo] with out*split_scale = hi + lo -- the A operand of out_proj run as a
  *            K-concatenated 3-product split GEMM on the f16 matrix cores (NULL to skip) */
 int rac_mixing_fwd(const float *x, const float *params, float param_scale, float *out, void *out_split,

@@ -17,7 +17,7 @@ __device__ __forceinline__ float aln_wave_sum(float v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a, int S, long pstride, int ld_a,
+__global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a, int S, long pstride, int ld_a, float a_scale,
                                                      const float *__restrict__ residual, const float *__restrict__ bias,
                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                                      const float *__restrict__ post, float *__restrict__ out, int ld_out,
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
                 const rac_f4 w = rac_ld4(a + (size_t)s * pstride + (size_t)row * ld_a + c * 4);
                 v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
             }
+            v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
             if (bias) {
                 const rac_f4 w = rac_ld4(bias + c * 4);
                 v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void pe_head_kernel(const float *__restrict__ 
     *reinterpret_cast<rac_f4 *>(out + (size_t)row * 256 + lane * 4) = y;
 }
 
-extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, const float *residual,
+extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, float a_scale, const float *residual,
                               const float *bias, const float *gamma, const float *beta, const float *post_residual,
                               float *out, int ld_out, int rows, int dim, float eps, int relu, void *split_out,
                               float split_scale, int split_pad, void *stream)
@@ -143,7 +144,7 @@ extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_
         return 0;
     RAC_CHECK_ARG(a && gamma && beta && out, "rac_add_ln_fwd: null pointer");
     hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, num_partials,
-                       (long)partial_stride, ld_a, residual, bias, gamma, beta, post_residual, out, ld_out, rows, dim, eps, relu,
+                       (long)partial_stride, ld_a, a_scale, residual, bias, gamma, beta, post_residual, out, ld_out, rows, dim, eps, relu,
                        reinterpret_cast<_Float16 *>(split_out), split_scale, split_pad);
     return rac_launch_status("rac_add_ln_fwd");
 }

@@ -143,8 +143,8 @@ def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range, box_table=None):
 def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5, split=False, param_scale=1.0, f16x3=False):
     """x [B,Q,G,P,64] (contiguous), params [B,Q,G*(64*64+128*P)] (unit inner stride) ->
     relu(LN(S @ relu(LN(x @ M)))) as [B,Q,G*128*64], ready for out_proj.
-    ``split=True``: instead returns the f16 image [B*Q, G*8, 3072] of the same values * SPLIT_ACT_SCALE, every
-    1024-wide K slice stored as [hi | hi | lo] (A operand of the split-K split-precision out_proj GEMM).
+    ``split=True``: instead returns the f16 image [B*Q, G*4, 3*2048] of the same values * SPLIT_ACT_SCALE, every
+    2048-wide K slice stored as [hi | hi | lo] (A operand of the split-K split-precision out_proj GEMM).
     ``param_scale``: factor applied to every parameter on load (the power-of-two alpha of a split generator GEMM).
     ``f16x3``: run the two products as 3-product split-precision f16 MFMAs (RAC_MIX_F16X3) instead of f32-input MFMAs."""
     _lib.require_gpu(x, what="mixing_fused")
@@ -154,7 +154,7 @@ def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5, split
     width = G * (C * C + out_points * P)
     p_par, ld_par = _rows(params, width, "mixing_fused(params)")
     if split:
-        out = torch.empty(B * Q, G * out_points * C // 1024, 3 * 1024, device=x.device, dtype=torch.float16)
+        out = torch.empty(B * Q, G * out_points * C // SPLIT_SLICE, 3 * SPLIT_SLICE, device=x.device, dtype=torch.float16)
     else:
         out = torch.empty(B, Q, G * out_points * C, device=x.device, dtype=torch.float32)
     ev = _lib.timer.record("mixing_fwd") if _lib.timer is not None else None
@@ -184,11 +184,13 @@ def refine_fused(proposal, delta, time_diff_safe, num_ray):
 
 
 SPLIT_ACT_SCALE = 16.0   # power of two applied to activations before the f16 hi/lo split (keeps lo out of f16 subnormals)
-SPLIT_BIAS_PAD = 8       # extra K columns of a split image that carry the bias ([1, 1, 0...] against [b_hi, b_lo, 0...])
+SPLIT_BIAS_PAD = 64      # extra K columns of a split image that carry the bias ([1, 1, 0...] against [b_hi, b_lo, 0...]);
+                         # 3*256 + 64 = 832 = 13 x 64 keeps hipBLASLt on its fast kernels (776: 187 us, 832: 134 us)
+SPLIT_SLICE = 2048       # K slice of rac_mixing_fwd's out_split image = split-K batch of out_proj
 
 
-def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=None, out=None, split=False):
-    """[relu](LayerNorm(sum_s a[s] + residual + bias)) [+ post] with ``norm`` an nn.LayerNorm; a is [..., dim]
+def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=None, out=None, split=False, a_scale=1.0):
+    """[relu](LayerNorm(a_scale * sum_s a[s] + residual + bias)) [+ post] with ``norm`` an nn.LayerNorm; a is [..., dim]
     (unit inner stride; rows may be a column slice of a wider tensor) or [S, ..., dim] with num_partials=S.
     ``out``: optional destination (may itself be a column slice).  One launch.
     ``split=True``: also returns the f16 [rows, 3*dim + SPLIT_BIAS_PAD] = [hi | hi | lo | 1 1 0..] image of
@@ -220,7 +222,7 @@ def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=N
             raise RuntimeError("add_ln: out must have unit inner stride and the normalised width")
         ld_out = out.stride(-2)
     split_out = torch.empty(rows, 3 * dim + SPLIT_BIAS_PAD, device=a.device, dtype=torch.float16) if split else None
-    rc = _lib.lib().rac_add_ln_fwd(_lib.ptr(a), num_partials, rows * dim, ld_a,
+    rc = _lib.lib().rac_add_ln_fwd(_lib.ptr(a), num_partials, rows * dim, ld_a, float(a_scale),
                                    _lib.ptr(residual) if residual is not None else None,
                                    _lib.ptr(bias) if bias is not None else None, _lib.ptr(norm.weight), _lib.ptr(norm.bias),
                                    _lib.ptr(post) if post is not None else None, _lib.ptr(out), ld_out, rows, dim,

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_SLICE, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
                     pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
 from .msda import msda_forward
 from .msmv import msmv_forward
@@ -501,7 +501,7 @@ class AdaptiveMixing(nn.Module):
     # ([hi | hi | lo] x [Whi | Wlo | Whi]); measured error vs float64 equals the fp32 GEMM's (tools/exp_splitgemm.py)
     # at 2.3x the fp32-MFMA GEMM rate.  Power-of-two scalings keep the lo parts out of f16 subnormals and are
     # undone exactly by the GEMM's alpha.
-    SPLIT_SLICE = 1024   # K slice of out_proj's split-K batches; fixed by rac_mixing_fwd's out_split layout
+    SPLIT_SLICE = SPLIT_SLICE   # K slice of out_proj's split-K batches; fixed by rac_mixing_fwd's out_split layout
 
     def split_packs(self, act_bound=None):
         """-> dict(gen_w [N,3K+8] f16, gen_alpha, out_w [S,256,3*1024] f16, out_alpha), or {} if f16 cannot hold the
@@ -530,7 +530,8 @@ class AdaptiveMixing(nn.Module):
         """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
         out_proj.  Returns the S partial products [S, B*Q, query_dim]; their sum + out_proj.bias + query
         is inner_forward's result (the caller folds that sum into its LayerNorm kernel).  ``params``:
-        the generator output if the caller already produced it (on a side stream).  ``packs`` +
+        the generator output if the caller already produced it (on a side stream); with ``packs`` the partials
+        still carry the power-of-two factor 1/packs["out_alpha"] (folded into the caller's add_ln).  ``packs`` +
         ``query_split`` ([B*Q, 3*query_dim] f16 from add_ln(split=True)): both GEMMs as split-precision
         f16-MFMA GEMMs (see split_packs)."""
         B, Q, G, P, C = x.shape
@@ -555,12 +556,8 @@ class AdaptiveMixing(nn.Module):
         if ev:
             ev[0].record()
         if split:
-            ow = packs["out_w"]                                            # [S, N, 3k]
-            zero = packs.get("zero")
-            if zero is None or zero.shape[1] != B * Q:
-                zero = packs["zero"] = torch.zeros(ow.shape[0], B * Q, ow.shape[1], device=x.device, dtype=torch.float32)
-            partials = torch.baddbmm(zero, out.transpose(0, 1), ow.transpose(1, 2), beta=0, alpha=packs["out_alpha"],
-                                     out_dtype=torch.float32)
+            # [S, B*Q, 3k] x [S, 3k, N]; the caller's add_ln applies packs["out_alpha"] to the summed partials
+            partials = torch.bmm(out.transpose(0, 1), packs["out_w"].transpose(1, 2), out_dtype=torch.float32)
         else:
             S_, N, k = out_proj_split.shape
             partials = torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
@@ -715,7 +712,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         sasa_w = self._cached("sasa", [at.attention.attn.in_proj_weight, at.gen_tau.weight, at.attention.attn.in_proj_bias,
                                        at.gen_tau.bias], at.wide_in_proj)
         packs = {}
-        if self.split_gemm and radar_value.is_cuda and self.fused:
+        if self.split_gemm and radar_value.is_cuda and self.fused and not self.tail_kernel:   # (the one-launch tail sums raw partials)
             # |norm1 output| <= sqrt(E) * max|gamma| + max|beta| bounds the generator's A operand
             packs = self._cached("split_packs", [mix.parameter_generator.weight, mix.parameter_generator.bias,
                                                  mix.out_proj.weight, self.norm1.weight, self.norm1.bias], lambda: mix.split_packs(
@@ -780,6 +777,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         if side is not None:
             torch.cuda.current_stream().wait_event(done)
         partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], params, packs, x1_split)
+        p_scale = packs["out_alpha"] if packs else 1.0
         if stages is None and self.tail_kernel and "tail" in prepared:
             # everything that remains of the layer in one launch (rac_layer_tail_fwd)
             x3, cls_score, bbox_pred, bbox_xy = layer_tail_fused(prepared["tail"], x1, bev[0], bev[1], partials, qb,
@@ -793,7 +791,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         add_ln(proj[0], self.norm_radar_bev, residual=x1, out=cat[..., E:2 * E])
         add_ln(proj[1], self.norm_lss_bev, residual=x1, out=cat[..., 2 * E:])
         add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0],
-               out=cat[..., :E])
+               out=cat[..., :E], a_scale=p_scale)
         f = add_ln(self.fusion(cat), self.norm_fusion)
         ffn_lin = self.ffn.layers[1](F.relu(self.ffn.layers[0][0](f)))
         x3 = add_ln(ffn_lin, self.norm3, residual=f)
@@ -808,7 +806,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         if stages is not None:
             stages.update(position_encoder=x - query_feat, self_attn=x + attn, sampling_radar_bev=proj[0] + x1,
                           sampling_lss_bev=proj[1] + x1, sampling=sampled_feat,
-                          mixing=x1 + partials.sum(0).view_as(x1) + self.mixing.out_proj.bias, ffn=f + ffn_lin)
+                          mixing=x1 + p_scale * partials.sum(0).view_as(x1) + self.mixing.out_proj.bias, ffn=f + ffn_lin)
         self.last_bbox_xy = bbox_xy
         return x3, cls_score, bbox_pred
 

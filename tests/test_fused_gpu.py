@@ -136,16 +136,16 @@ def test_refine_and_add_ln_kernels():
     pred, xy = refine_fused(prop.to(DEV), delta.to(DEV), td_safe.to(DEV), 150)
     assert (pred.cpu() - ref).abs().max().item() < 1e-5
     assert (xy.cpu() - R.theta_d2xy(ref)).abs().max().item() < 1e-5
-    for dim, S, relu in ((256, 1, False), (256, 32, True), (512, 3, False), (1024, 1, True)):
+    for dim, S, relu, scale in ((256, 1, False, 1.0), (256, 32, True, 0.25), (512, 3, False, 1.0), (1024, 1, True, 2.0)):
         ln = torch.nn.LayerNorm(dim)
         torch.nn.init.normal_(ln.weight)
         torch.nn.init.normal_(ln.bias)
         a, res, bias = torch.randn(S, 5, 41, dim), torch.randn(5, 41, dim), torch.randn(dim)
-        want = ln(a.sum(0) + res + bias)
+        want = ln(scale * a.sum(0) + res + bias)
         want = torch.relu(want) if relu else want
         lg = ln.to(DEV)
         got = add_ln(a.to(DEV) if S > 1 else a[0].to(DEV), lg, residual=res.to(DEV), bias=bias.to(DEV), relu=relu,
-                     num_partials=S)
+                     num_partials=S, a_scale=scale)
         assert (got.cpu() - want.detach()).abs().max().item() < 2e-5, (dim, S)
         ln.cpu()
 
@@ -203,15 +203,15 @@ def test_sasa_kernels_all_sizes(Q):
 def test_split_precision_operands_and_gemms():
     """The f16 hi/lo images written by rac_add_ln_fwd / rac_mixing_fwd reproduce the fp32 values to 2^-21, and the
     K-concatenated 3-product GEMMs built on them match a float64 GEMM as closely as the fp32 GEMM does."""
-    from racformer_amd.fused import SPLIT_ACT_SCALE, add_ln, mixing_fused, split_weight_f16
+    from racformer_amd.fused import SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, add_ln, mixing_fused, split_weight_f16
     from racformer_amd.transformer import AdaptiveMixing
     torch.manual_seed(5)
     ln = torch.nn.LayerNorm(256).to(DEV)
     a, res = torch.randn(1, 900, 256, device=DEV), torch.randn(1, 900, 256, device=DEV)
     out, img = add_ln(a, ln, residual=res, split=True)
-    assert img.dtype == torch.float16 and tuple(img.shape) == (900, 776)
-    hi, hi2, lo, pad = img.float().split([256, 256, 256, 8], dim=1)
-    assert torch.equal(pad, torch.tensor([SPLIT_ACT_SCALE] * 2 + [0.0] * 6, device=DEV).expand(900, 8))
+    assert img.dtype == torch.float16 and tuple(img.shape) == (900, 768 + SPLIT_BIAS_PAD)
+    hi, hi2, lo, pad = img.float().split([256, 256, 256, SPLIT_BIAS_PAD], dim=1)
+    assert torch.equal(pad, torch.tensor([SPLIT_ACT_SCALE] * 2 + [0.0] * (SPLIT_BIAS_PAD - 2), device=DEV).expand(900, SPLIT_BIAS_PAD))
     assert torch.equal(hi, hi2)
     rec = (hi.double() + lo.double()) / SPLIT_ACT_SCALE
     assert (rec - out.view(900, 256).double()).abs().max().item() <= 2.0 ** -21 * out.abs().max().item()
@@ -230,14 +230,13 @@ def test_split_precision_operands_and_gemms():
         params = mix.parameter_generator(q)
         z = mixing_fused(x, params, 96, 4, 128)
         z16 = mixing_fused(x, params, 96, 4, 128, split=True)
-        assert tuple(z16.shape) == (64, 32, 3072)
-        zh, zh2, zl = z16.float().view(64, 32, 3, 1024).unbind(2)
+        assert tuple(z16.shape) == (64, 32768 // SPLIT_SLICE, 3 * SPLIT_SLICE)
+        zh, zh2, zl = z16.float().view(64, 32768 // SPLIT_SLICE, 3, SPLIT_SLICE).unbind(2)
         assert torch.equal(zh, zh2)
         rec = ((zh.double() + zl.double()) / SPLIT_ACT_SCALE).reshape(64, -1)
         assert (rec - z.view(64, -1).double()).abs().max().item() <= 2.0 ** -21 * z.abs().max().item()
         packs = mix.split_packs()
-        part = torch.baddbmm(torch.zeros(32, 64, 256, device=DEV), z16.transpose(0, 1), packs["out_w"].transpose(1, 2),
-                             beta=0, alpha=packs["out_alpha"], out_dtype=torch.float32)
+        part = torch.bmm(z16.transpose(0, 1), packs["out_w"].transpose(1, 2), out_dtype=torch.float32) * packs["out_alpha"]
         want = z.view(64, -1).double() @ mix.out_proj.weight.double().t()
         e_split = (part.sum(0).double() - want).abs().max().item()
         e_fp32 = ((z.view(64, -1) @ mix.out_proj.weight.t()).double() - want).abs().max().item()

@@ -88,7 +88,7 @@ def test_c_abi_argument_errors_without_gpu():
     rc = lib.rac_bev_sampling_fwd(p8, p8, p8, p8, p8, p8, p8, p8, p8, None, 160, 5, 80, 8, 1, 8, 900, 4, 9, 5, 128, 128, 64,
                                   pc, db, 0.08, 0, None)
     assert rc == -1 and b"staging roles" in lib.rac_last_error()
-    rc = lib.rac_add_ln_fwd(p8, 1, 0, 258, None, None, p8, p8, None, p8, 258, 4, 258, 1e-5, 0, None, 1.0, 0, None)
+    rc = lib.rac_add_ln_fwd(p8, 1, 0, 258, 1.0, None, None, p8, p8, None, p8, 258, 4, 258, 1e-5, 0, None, 1.0, 0, None)
     assert rc == -1 and b"dim" in lib.rac_last_error()
     # empty problems return success before touching any pointer
     assert lib.rac_msmv_fwd(None, None, 4, None, None, None, 0, 6, 900, 12, 64, 0, 0, 1, 1, None) == 0

@@ -32,6 +32,8 @@
  *                        models/racformer_transformer.py:589-603
  *   rac_sasa_fwd      <- ScaleAdaptiveSelfAttention.inner_forward's mask + attention product
  *                        models/racformer_transformer.py:296-335
+ *   rac_absmax_fwd / rac_conv_pack_fwd / rac_conv3x3_fwd <- RadarBEVTemporalEncoder.temporal_fusion (nn.Conv2d 3x3)
+ *                        models/racformer_transformer.py:631,655
  *   rac_bev_sampling_fwd <- BEVSampling keypoints + BEVSelfAttention's MSDA + frame fusion, fused
  *                        models/racformer_transformer.py:490-529, models/bev_self_attention.py:176-213
  */
@@ -207,6 +209,24 @@ enum {
 int rac_mixing_fwd(const float *x, const float *params, float param_scale, float *out, void *out_split,
                    float split_scale, int ld_params, int num_query, int groups, int in_points, int channels, int out_points,
                    float eps, int mfma_mode, void *stream);
+
+/* The temporal-fusion convolution of RadarBEVTemporalEncoder (3x3, stride 1, pad 1, Cin -> 256; the 193-GFLOP
+ * nn.Conv2d of models/racformer_transformer.py:631,655) as an implicit GEMM on the f16 matrix cores with
+ * hi/lo-split operands (3 products, fp32 accumulate: fp32-convolution accuracy).  Three calls:
+ *   rac_absmax_fwd    amax_out[0] = max |v| over `num` device arrays (srcs / counts: HOST arrays; 16-byte aligned
+ *                     sources); enqueues a memset of amax_out first.  Fixes the activations' power-of-two scale.
+ *   rac_conv_pack_fwd src [N,C,H,W] f32 -> channel range [c_offset, c_offset+C) of the kernel's activation image
+ *                     xs = f16 [N][H+2][W+2][c_total/32][2][32] (per pixel and 32-channel chunk: hi, then lo, of
+ *                     v * 2^e; e from *amax).  Only interior pixels are written: the caller zeroes xs once (border =
+ *                     the convolution's zero padding).  W % 4 == 0, W <= 128, channel counts multiples of 32.
+ *   rac_conv3x3_fwd   out [N,H,W,256] f32 (channel-last) = conv3x3(xs) * w_alpha / 2^e + bias, with
+ *                     ws = f16 [9 taps (ky*3+kx)][Cin/32][256][2][32] holding hi / lo of weight[co][ci][ky][kx] / w_alpha
+ *                     (w_alpha a power of two chosen by the packer).  H*W must be a multiple of 256. */
+int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float *amax_out, void *stream);
+int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, int N, int C, int H, int W, int c_total,
+                      int c_offset, void *stream);
+int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
+                    int N, int H, int W, int Cin, int Cout, void *stream);
 
 /* Backward of the two gather operators (SURVEY.md section 8 "next" row f4; fp32 features only).
  * rac_msmv_bwd  <- _ms_deform_attn_cuda_{c45,c2345,c23456}_backward, models/csrc/msmv_sampling/msmv_sampling.cpp:302-497

@@ -1,0 +1,278 @@
+// conv3x3.hip -- the temporal-fusion convolution of RadarBEVTemporalEncoder (3x3, stride 1, pad 1, 320 -> 256
+// channels on 8 x 128 x 128 BEV maps: 193 of the encoder's 220 GFLOP; models/racformer_transformer.py:645-656) as an
+// implicit GEMM on the f16 matrix cores at fp32-GEMM accuracy (gfx950).
+//
+// Arithmetic: every activation and weight is split as v * 2^e = hi + lo (two f16, 22 significant bits) and the
+// three leading products hi*hi + hi*lo + lo*hi are accumulated in fp32 by v_mfma_f32_16x16x32_f16 -- the dropped
+// lo*lo term is 2^-22 relative, the result matches an fp32 convolution to fp32 rounding.  The power of two 2^e
+// of the activations is derived on the device from their max |value| (rac_absmax_fwd), so no input magnitude can
+// overflow f16; the weights' 2^e is chosen by the host when it packs them.  Three f16 MFMA products cost 3/16 of
+// the f32-input MFMA time of the same GEMM.
+//
+// Layouts (all built for this kernel):
+//   activations  xs [N][H+2][W+2][Cin/32][2][32] f16  zero border (the conv's padding), per pixel and 32-channel
+//                chunk 64 B of hi then 64 B of lo: one K-step's A row is one 128-byte line
+//   weights      ws [9 taps][Cin/32][Cout=256][2][32] f16: one K-step's B tile is 32 KB contiguous
+//   output       out [N][H][W][256] f32 (channel-last: what value_proj's GEMM reads as its A operand)
+// Workgroup = 512 threads = 8 waves (2 along pixels x 4 along channels), tile = 256 consecutive pixels of one
+// image x 256 output channels, K loop over 9 taps x Cin/32 chunks.  Per K-step 64 KB (A 32 KB + B 32 KB) go
+// global -> registers -> LDS (two LDS stages = 128 KB, the loads of step k+1 are issued before the MFMAs of
+// step k and written after them; one barrier per step), fragments are 16-byte LDS reads made conflict-free by an
+// XOR swizzle of the 16-byte slots (slot ^ ((row >> 1) & 7)), 96 MFMAs per wave and step.
+#include "rac_common.h"
+
+typedef _Float16 cv_h8 __attribute__((ext_vector_type(8)));
+typedef float cv_f4 __attribute__((ext_vector_type(4)));
+
+#define CV_TM 256
+#define CV_COUT 256
+#define CV_STAGE_U4 4096 /* uint4 per LDS stage: A 2048 + B 2048 */
+
+// power of two that brings amax into [2^13, 2^14) (1 for amax == 0 or non-finite input)
+__device__ __forceinline__ float cv_act_scale(float amax)
+{
+    if (!(amax > 1.0e-30f) || !(amax < 3.0e38f))
+        return 1.f;
+    const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 126;   // amax = m * 2^ex, m in [0.5, 1)
+    return __uint_as_float((unsigned)(14 - ex + 127) << 23);             // 2^(14 - ex)
+}
+
+// ------------------------------------------------------------------------------------------------ absmax
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ src, long n, unsigned *__restrict__ out)
+{
+    float m = 0.f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const rac_f4 v = rac_ld4(src + i * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+        m = fmaxf(m, fabsf(src[n4 * 4 + threadIdx.x]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        m = fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pack
+// [N][C][H][W] f32 -> channel chunks chunk0.. of xs (interior pixels only; the border stays zero)
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ src, const float *__restrict__ amax,
+                                                        _Float16 *__restrict__ dst, int C, int H, int W, int chunks_total,
+                                                        int chunk0)
+{
+    __shared__ float tile[32][129];
+    const int cchunks = C >> 5;
+    const int c32 = blockIdx.x % cchunks;
+    const int h = (blockIdx.x / cchunks) % H;
+    const int n = blockIdx.x / (cchunks * H);
+    const int tid = threadIdx.x;
+    const float scale = cv_act_scale(*amax);
+    const int w4n = W >> 2;
+    for (int i = tid; i < 32 * w4n; i += 256) {
+        const int ch = i / w4n, w4 = i - ch * w4n;
+        const rac_f4 v = rac_ld4(src + (((size_t)n * C + c32 * 32 + ch) * H + h) * W + w4 * 4);
+        tile[ch][w4 * 4 + 0] = v.x;
+        tile[ch][w4 * 4 + 1] = v.y;
+        tile[ch][w4 * 4 + 2] = v.z;
+        tile[ch][w4 * 4 + 3] = v.w;
+    }
+    __syncthreads();
+    for (int i = tid; i < W * 8; i += 256) {
+        const int w = i >> 3, s = i & 7, c0 = (s & 3) * 8;
+        cv_h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = tile[c0 + j][w] * scale;
+            const _Float16 hi = (_Float16)v;
+            o[j] = s < 4 ? hi : (_Float16)(v - (float)hi);
+        }
+        const size_t pix = ((size_t)n * (H + 2) + h + 1) * (W + 2) + w + 1;
+        *reinterpret_cast<cv_h8 *>(dst + (pix * chunks_total + chunk0 + c32) * 64 + s * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv
+struct ConvArgs {
+    const uint4 *xs;
+    const uint4 *ws;
+    const float *bias;
+    const float *amax;
+    float *out;
+    int N, H, W, chunks;
+    float w_alpha;
+};
+
+__global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
+{
+    extern __shared__ uint4 lds4[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int H = a.H, W = a.W, Wp = W + 2, chunks = a.chunks;
+    const int tiles_per_img = (H * W) / CV_TM;
+    const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
+    const int KS = 9 * chunks;
+    const size_t pix_stride = (size_t)chunks * 8;   // uint4 per pixel
+
+    // staging role: 16-byte slot (tid & 7) of rows (tid >> 3) + 64 j of both the A and the B tile
+    auto row_base = [&](int j) -> size_t {
+        const int r = (tid >> 3) + 64 * j;
+        const int gp = tile * CV_TM + r, h = gp / W, w = gp - h * W;
+        return (((size_t)n * (H + 2) + h) * Wp + w) * pix_stride + (tid & 7);
+    };
+    auto row_slot = [&](int j) -> int {
+        const int r = (tid >> 3) + 64 * j;
+        return r * 8 + ((tid & 7) ^ ((r >> 1) & 7));
+    };
+    const size_t a_base0 = row_base(0), a_base1 = row_base(1), a_base2 = row_base(2), a_base3 = row_base(3);
+    const int st0 = row_slot(0), st1 = row_slot(1), st2 = row_slot(2), st3 = row_slot(3);
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define CV_GLOAD(ks_)                                                                          \
+    do {                                                                                       \
+        const int tap_ = (ks_) / chunks, chunk_ = (ks_) - tap_ * chunks;                       \
+        const int dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;                                        \
+        const size_t off_ = ((size_t)dy_ * Wp + dx_) * pix_stride + (size_t)chunk_ * 8;        \
+        const uint4 *wsrc_ = a.ws + (size_t)(ks_) * 2048 + tid;                                \
+        ra0 = a.xs[a_base0 + off_]; ra1 = a.xs[a_base1 + off_];                            \
+        ra2 = a.xs[a_base2 + off_]; ra3 = a.xs[a_base3 + off_];                            \
+        rb0 = wsrc_[0]; rb1 = wsrc_[512]; rb2 = wsrc_[1024]; rb3 = wsrc_[1536];        \
+    } while (0)
+#define CV_LSTORE(buf_)                                                                        \
+    do {                                                                                       \
+        uint4 *A_ = lds4 + (buf_) * CV_STAGE_U4, *B_ = A_ + 2048;                              \
+        A_[st0] = ra0; A_[st1] = ra1; A_[st2] = ra2; A_[st3] = ra3;                    \
+        B_[st0] = rb0; B_[st1] = rb1; B_[st2] = rb2; B_[st3] = rb3;                    \
+    } while (0)
+
+    cv_f4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+            acc[m][nn] = (cv_f4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment slots: row = base + li, hi slot lk, lo slot 4 + lk, both XOR-swizzled with (row >> 1) & 7
+    int bidx_h[4], bidx_l[4];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+        const int row = 64 * wn + 16 * nn + li, f = (row >> 1) & 7;
+        bidx_h[nn] = 2048 + row * 8 + (lk ^ f);
+        bidx_l[nn] = 2048 + row * 8 + ((4 + lk) ^ f);
+    }
+    const int arow0 = 128 * wm + li;
+
+    CV_GLOAD(0);
+    CV_LSTORE(0);
+    __syncthreads();
+    for (int ks = 0; ks < KS; ++ks) {
+        // (the last step re-fetches its own tile: unconditional loads keep the staging registers out of scratch)
+        const int kn = ks + 1 < KS ? ks + 1 : ks;
+        CV_GLOAD(kn);
+        const cv_h8 *S = reinterpret_cast<const cv_h8 *>(lds4 + (ks & 1) * CV_STAGE_U4);
+        cv_h8 bh[4], bl[4];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            bh[nn] = S[bidx_h[nn]];
+            bl[nn] = S[bidx_l[nn]];
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int row = arow0 + 16 * m, f = (row >> 1) & 7;
+            const cv_h8 ah = S[row * 8 + (lk ^ f)];
+            const cv_h8 al = S[row * 8 + ((4 + lk) ^ f)];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nn], acc[m][nn], 0, 0, 0);
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nn], acc[m][nn], 0, 0, 0);
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nn], acc[m][nn], 0, 0, 0);
+        }
+        CV_LSTORE((ks + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: undo the two power-of-two scalings, add the bias, channel-last store
+    const float unscale = a.w_alpha / cv_act_scale(*a.amax);
+    float *obase = a.out + ((size_t)n * H * W + (size_t)tile * CV_TM) * CV_COUT;
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+        const int col = 64 * wn + 16 * nn + li;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = 128 * wm + 16 * m + 4 * lk + r;
+                obase[(size_t)p * CV_COUT + col] = acc[m][nn][r] * unscale + bv;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+extern "C" int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float *amax_out, void *stream)
+{
+    RAC_CHECK_ARG(num >= 0 && amax_out, "rac_absmax_fwd: bad arguments");
+    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) {
+        rac_set_error("rac_absmax_fwd: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    for (int i = 0; i < num; ++i) {
+        RAC_CHECK_ARG(counts[i] >= 0 && (counts[i] == 0 || srcs[i]), "rac_absmax_fwd: source %d", i);
+        RAC_CHECK_ARG(((uintptr_t)srcs[i] & 15) == 0, "rac_absmax_fwd: source %d is not 16-byte aligned", i);
+        if (counts[i] == 0)
+            continue;
+        long blocks = (counts[i] / 4 + 255) / 256;
+        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, srcs[i], (long)counts[i],
+                           reinterpret_cast<unsigned *>(amax_out));
+    }
+    return rac_launch_status("rac_absmax_fwd");
+}
+
+extern "C" int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, int N, int C, int H, int W, int c_total,
+                                 int c_offset, void *stream)
+{
+    RAC_CHECK_ARG(N >= 0 && C > 0 && C % 32 == 0 && c_total % 32 == 0 && c_offset % 32 == 0 && c_offset + C <= c_total,
+                  "rac_conv_pack_fwd: channels C=%d c_total=%d c_offset=%d (multiples of 32)", C, c_total, c_offset);
+    RAC_CHECK_ARG(H > 0 && W >= 4 && W <= 128 && W % 4 == 0, "rac_conv_pack_fwd: W=%d (multiple of 4, <= 128)", W);
+    if (N == 0)
+        return 0;
+    RAC_CHECK_ARG(src && amax && xs, "rac_conv_pack_fwd: null pointer");
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)(N * H * (C / 32))), dim3(256), 0, (hipStream_t)stream, src, amax,
+                       reinterpret_cast<_Float16 *>(xs), C, H, W, c_total / 32, c_offset / 32);
+    return rac_launch_status("rac_conv_pack_fwd");
+}
+
+extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha,
+                               float *out, int N, int H, int W, int Cin, int Cout, void *stream)
+{
+    RAC_CHECK_ARG(Cout == CV_COUT, "rac_conv3x3_fwd: built for %d output channels (got %d)", CV_COUT, Cout);
+    RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "rac_conv3x3_fwd: Cin=%d (multiple of 32)", Cin);
+    RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0 && (H * W) % CV_TM == 0, "rac_conv3x3_fwd: H*W=%d must be a multiple of %d", H * W, CV_TM);
+    if (N == 0)
+        return 0;
+    RAC_CHECK_ARG(xs && ws && amax && out, "rac_conv3x3_fwd: null pointer");
+    ConvArgs a;
+    a.xs = reinterpret_cast<const uint4 *>(xs);
+    a.ws = reinterpret_cast<const uint4 *>(ws);
+    a.bias = bias; a.amax = amax; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha;
+    const int lds = 2 * CV_STAGE_U4 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_f16x3_kernel, dim3((unsigned)(N * (H * W / CV_TM))), dim3(512), lds, (hipStream_t)stream, a);
+    return rac_launch_status("rac_conv3x3_fwd");
+}

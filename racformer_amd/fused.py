@@ -328,3 +328,60 @@ def layer_tail_fused(tw, x1, bev_r, bev_l, partials, query_bbox, time_diff_safe,
         ev[1].record()
     _lib.check(rc, "rac_layer_tail_fwd")
     return x3, cls, pred, xy
+
+
+# ------------------------------------------------------------------------------------------- 3x3 convolution
+def pack_conv3x3_weight(weight):
+    """nn.Conv2d weight [256, Cin, 3, 3] fp32 -> (ws f16 [9, Cin/32, 256, 2, 32], w_alpha) for rac_conv3x3_fwd:
+    hi / lo of weight * 2^s per (tap, 32-channel chunk, output channel), w_alpha = 2^-s.  (None, None) if the
+    weights cannot be held."""
+    import math
+    w = weight.detach().float()
+    co, ci, kh, kw = w.shape
+    amax = float(w.abs().max())
+    if (kh, kw) != (3, 3) or co != 256 or ci % 32 != 0 or not (amax > 0.0) or amax != amax or amax == float("inf"):
+        return None, None
+    s = 13 - math.frexp(amax)[1] + 1
+    ws = (w * (2.0 ** s)).permute(2, 3, 1, 0).reshape(9, ci // 32, 32, co).permute(0, 1, 3, 2)      # [tap, chunk, co, 32]
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    return torch.stack([hi, lo], dim=3).contiguous(), 2.0 ** (-s)
+
+
+_conv_images = {}
+
+
+def conv3x3_fused(sources, ws, w_alpha, bias):
+    """3x3 / stride 1 / pad 1 convolution of the channel concatenation of ``sources`` (NCHW fp32 tensors with
+    equal N, H, W) -> [N, H, W, 256] fp32 channel-last.  absmax -> pack (NCHW fp32 -> padded channel-last f16
+    hi/lo image) -> implicit-GEMM kernel; the padded image buffer is allocated (zeroed) once per shape."""
+    _lib.require_gpu(*sources, ws, what="conv3x3_fused")
+    N, _, H, W = sources[0].shape
+    cin = sum(int(t.shape[1]) for t in sources)
+    dev = sources[0].device
+    key = (N, H, W, cin, str(dev))
+    xs = _conv_images.get(key)
+    if xs is None:
+        xs = _conv_images[key] = torch.zeros(N, H + 2, W + 2, cin // 32, 2, 32, device=dev, dtype=torch.float16)
+    amax = torch.empty(1, device=dev, dtype=torch.float32)
+    n = len(sources)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in sources])
+    counts = (ctypes.c_int64 * n)(*[t.numel() for t in sources])
+    L = _lib.lib()
+    ev = _lib.timer.record("temporal_fusion_conv") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    _lib.check(L.rac_absmax_fwd(ptrs, counts, n, _lib.ptr(amax), _lib.stream_ptr()), "rac_absmax_fwd")
+    off = 0
+    for t in sources:
+        if tuple(t.shape[0:1] + t.shape[2:]) != (N, H, W) or t.dtype != torch.float32:
+            raise RuntimeError("conv3x3_fused: sources must be float32 [N,C,H,W] with equal N, H, W")
+        _lib.check(L.rac_conv_pack_fwd(_lib.ptr(t), _lib.ptr(amax), _lib.ptr(xs), N, int(t.shape[1]), H, W, cin, off,
+                                       _lib.stream_ptr()), "rac_conv_pack_fwd")
+        off += int(t.shape[1])
+    out = torch.empty(N, H, W, 256, device=dev, dtype=torch.float32)
+    _lib.check(L.rac_conv3x3_fwd(_lib.ptr(xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None, _lib.ptr(amax),
+                                 float(w_alpha), _lib.ptr(out), N, H, W, cin, 256, _lib.stream_ptr()), "rac_conv3x3_fwd")
+    if ev:
+        ev[1].record()
+    return out

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_SLICE, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_SLICE, conv3x3_fused, pack_conv3x3_weight, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
                     pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
 from .msda import msda_forward
 from .msmv import msmv_forward
@@ -306,14 +306,35 @@ class RadarBEVTemporalEncoder(nn.Module):
     def init_weights(self):
         pass
 
-    def forward(self, bev_feats):
+    def hidden_stream(self, bev_feats):
+        """downsample -> ConvGRU -> upsample: [B,T,C,H,W] -> ([B*T,C,H,W] view of the input, [B*T,hidden,H,W])."""
         B, T, C, H, W = bev_feats.shape
         r = self.downsample_ratio
         x = bev_feats.flatten(0, 1)   # NCHW: an NHWC (channels_last) pipeline measured 3 % slower end to end
         down = self.downsample(x).reshape(B, T, self.hidden_dims, H // r, W // r)
-        hid = self.upsample(self.convGRU(down).flatten(0, 1))
+        return x, self.upsample(self.convGRU(down).flatten(0, 1))
+
+    def forward(self, bev_feats):
+        B, T, C, H, W = bev_feats.shape
+        x, hid = self.hidden_stream(bev_feats)
         cat = torch.cat([x, hid], dim=1)
         return self.temporal_fusion(cat).reshape(B, T, C, H, W)
+
+    # temporal_fusion (193 of the encoder's 220 GFLOP) on the hand-written implicit-GEMM kernel (rac_conv3x3_fwd:
+    # f16 matrix cores, hi/lo-split operands, fp32-convolution accuracy); no concatenation, no layout transposes,
+    # output already channel-last for value_proj.
+    fused_conv = True
+
+    def fused_conv_supported(self, bev_feats):
+        B, T, C, H, W = bev_feats.shape
+        return (self.fused_conv and bev_feats.is_cuda and bev_feats.dtype == torch.float32 and self.embed_dims == 256
+                and C == 256 and self.hidden_dims % 32 == 0 and (H * W) % 256 == 0 and W % 4 == 0 and W <= 128
+                and self.temporal_fusion.kernel_size == (3, 3) and self.temporal_fusion.padding == (1, 1))
+
+    def forward_channel_last(self, bev_feats, packed):
+        """-> [B*T, H, W, C] (channel-last).  ``packed`` = pack_conv3x3_weight(temporal_fusion.weight)."""
+        x, hid = self.hidden_stream(bev_feats)
+        return conv3x3_fused([x.contiguous(), hid.contiguous()], packed[0], packed[1], self.temporal_fusion.bias)
 
 
 class BEVSelfAttention(nn.Module):
@@ -339,20 +360,24 @@ class BEVSelfAttention(nn.Module):
             nn.init.xavier_uniform_(m.weight)
             nn.init.constant_(m.bias, 0.0)
 
-    def project_value(self, value_maps, pos=None):
-        """value_maps [B,T,C,H,W] (+ optional positional map [C,H,W] added to every frame) ->
+    def project_value(self, value_maps, pos=None, channel_last=False):
+        """value_maps [B,T,C,H,W] ([B,T,H,W,C] with channel_last) (+ optional positional map [C,H,W] added to every frame) ->
         [B*T, H*W, heads, C/heads] (bev_self_attention.py:162-174).  Query-independent: the decoder
         calls this once per forward, not once per layer.  value_proj is linear, so
         value_proj(bev + pos) = bev^T W^T + (pos^T W^T + b): the frame-independent term is projected
         once ([HW,C] GEMM) and enters as the GEMM's additive operand, and the [C,HW] -> [HW,C]
         transpose is the GEMM's own operand transposition -- no bev+pos tensor, no permute copy."""
-        B, T, C, H, W = value_maps.shape
+        if channel_last:
+            B, T, H, W, C = value_maps.shape
+        else:
+            B, T, C, H, W = value_maps.shape
         wt = self.value_proj.weight.t()
         if pos is None:
             bias = self.value_proj.bias.view(1, 1, C).expand(B * T, H * W, C)
         else:
             bias = self.value_proj(pos.reshape(C, H * W).t()).unsqueeze(0).expand(B * T, H * W, C)
-        v = torch.baddbmm(bias, value_maps.reshape(B * T, C, H * W).transpose(1, 2), wt.unsqueeze(0).expand(B * T, C, C))
+        a = value_maps.reshape(B * T, H * W, C) if channel_last else value_maps.reshape(B * T, C, H * W).transpose(1, 2)
+        v = torch.baddbmm(bias, a, wt.unsqueeze(0).expand(B * T, C, C))
         return v.view(B * T, H * W, self.num_heads, C // self.num_heads)
 
     def attend(self, query, value, sampling_locations, attention_weights, spatial_shapes, identity=None):
@@ -410,13 +435,18 @@ class BEVSampling(nn.Module):
         nn.init.uniform_(bias[:, 0:2], -0.5, 0.5)
         self.attention.init_weights()
 
-    def prepare_value(self, bev_feats):
+    def prepare_value(self, bev_feats, conv_pack=None):
         """Query-independent half of inner_forward (:484-485, :532-537 + value_proj): temporal
-        encoder (radar only), + learned positional encoding, value projection."""
-        if self.temp_radar:
-            bev_feats = self.temporal_encoder(bev_feats)
+        encoder (radar only), + learned positional encoding, value projection.  ``conv_pack``: the packed
+        temporal_fusion weights (fused convolution kernel, channel-last output) or None (MIOpen)."""
         H, W = bev_feats.shape[-2:]
         pos = self.positional_encoding.grid(H, W).to(bev_feats.dtype)
+        if self.temp_radar:
+            if conv_pack is not None and conv_pack[0] is not None and self.temporal_encoder.fused_conv_supported(bev_feats):
+                B, T = bev_feats.shape[:2]
+                nhwc = self.temporal_encoder.forward_channel_last(bev_feats, conv_pack)
+                return self.attention.project_value(nhwc.view(B, T, H, W, -1), pos, channel_last=True), (H, W)
+            bev_feats = self.temporal_encoder(bev_feats)
         return self.attention.project_value(bev_feats, pos), (H, W)
 
     def keypoints(self, query_ray, query_feat, time_diff, d_region):
@@ -695,7 +725,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
 
     def prepare(self, lss_bev_feats, radar_bev_feats):
         """Layer-invariant tensors (computed once per forward)."""
-        radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats)
+        te = self.sampling_radar_bev.temporal_encoder
+        conv_pack = self._cached("conv_pack", [te.temporal_fusion.weight], lambda: pack_conv3x3_weight(te.temporal_fusion.weight)) \
+            if radar_bev_feats.is_cuda and self.fused and te.fused_conv else None
+        radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack)
         lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
         rb, lb, mix = self.sampling_radar_bev, self.sampling_lss_bev, self.mixing
         wide_mods = [self.sampling.sampling_offset, self.sampling.ray_points_offset, self.sampling.scale_weights]

@@ -264,3 +264,30 @@ def test_split_gemm_decoder_matches_fp32_gemm_decoder(cfg):
     from parity import decoder_parity
     decoder_parity(outs[True][0], outs[True][1], outs[False][0].cpu(), outs[False][1].cpu(), what="split vs fp32 GEMMs")
     assert (outs[True][1][0] - outs[False][1][0]).abs().max().item() < 1e-4     # layer 0: no upstream divergence
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 128, 256, 64), (3, 16, 16, 256, 64), (2, 32, 64, 32, 32)])
+def test_conv3x3_fused_matches_fp32_conv(shape):
+    """rac_absmax/conv_pack/conv3x3 (implicit GEMM, f16 MFMA on hi/lo-split operands) vs a float64 convolution on
+    the CPU (small) or vs MIOpen's fp32 convolution (full size), incl. huge / tiny magnitudes (device-side scale)."""
+    from racformer_amd.fused import conv3x3_fused, pack_conv3x3_weight
+    N, H, W, C1, C2 = shape
+    torch.manual_seed(N)
+    conv = torch.nn.Conv2d(C1 + C2, 256, 3, padding=1)
+    for mag in (1.0, 3.0e7, 1.0e-9):
+        x1, x2 = torch.randn(N, C1, H, W) * mag, torch.randn(N, C2, H, W) * mag * 0.5
+        ws, alpha = pack_conv3x3_weight(conv.weight.to(DEV))
+        got = conv3x3_fused([x1.to(DEV), x2.to(DEV)], ws, alpha, conv.bias.detach().to(DEV))
+        assert tuple(got.shape) == (N, H, W, 256)
+        with torch.no_grad():
+            if N * H * W <= 4096:
+                want = torch.nn.functional.conv2d(torch.cat([x1, x2], 1).double(), conv.weight.double(), conv.bias.double(),
+                                                  padding=1).permute(0, 2, 3, 1)
+                tol = 4e-6
+            else:
+                want = conv.to(DEV)(torch.cat([x1, x2], 1).to(DEV)).permute(0, 2, 3, 1).double().cpu()
+                conv.cpu()
+                tol = 2e-5      # two fp32-grade results against each other
+        scale = want.abs().max().item()
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err <= tol * scale, (shape, mag, err, scale)

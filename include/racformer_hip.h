@@ -32,6 +32,8 @@
  *                        models/racformer_transformer.py:589-603
  *   rac_sasa_fwd      <- ScaleAdaptiveSelfAttention.inner_forward's mask + attention product
  *                        models/racformer_transformer.py:296-335
+ *   rac_gru_gate_fwd / rac_upsample2x_fwd <- ConvGRUCell.forward's element-wise tail, nn.Upsample
+ *                        models/racformer_transformer.py:705-720, :633-636
  *   rac_absmax_fwd / rac_conv_pack_fwd / rac_conv3x3_fwd <- RadarBEVTemporalEncoder.temporal_fusion (nn.Conv2d 3x3)
  *                        models/racformer_transformer.py:631,655
  *   rac_bev_sampling_fwd <- BEVSampling keypoints + BEVSelfAttention's MSDA + frame fusion, fused
@@ -227,6 +229,16 @@ int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, int N, int 
                       int c_offset, void *stream);
 int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
                     int N, int H, int W, int Cin, int Cout, void *stream);
+
+/* Element-wise pieces of RadarBEVTemporalEncoder (models/racformer_transformer.py:618-720).
+ *   rac_gru_gate_fwd   ConvGRUCell update after the gates convolution (:705-720): gates [B,3C,H,W] (z | r | cand),
+ *                      h_prev [B,C,H,W] (batch stride h_prev_bstride floats) -> h_out (batch stride h_out_bstride):
+ *                      h = (1 - sigmoid(z)) * h_prev + sigmoid(z) * tanh(cand + sigmoid(r) * h_prev)
+ *   rac_upsample2x_fwd nn.Upsample(scale_factor=2, bilinear, align_corners=True) (:633-636) on `planes` = N*C maps
+ *                      [h,w] -> [2h,2w] */
+int rac_gru_gate_fwd(const float *gates, const float *h_prev, int64_t h_prev_bstride, float *h_out, int64_t h_out_bstride,
+                     int B, int C, int HW, void *stream);
+int rac_upsample2x_fwd(const float *src, float *dst, int64_t planes, int h, int w, void *stream);
 
 /* Backward of the two gather operators (SURVEY.md section 8 "next" row f4; fp32 features only).
  * rac_msmv_bwd  <- _ms_deform_attn_cuda_{c45,c2345,c23456}_backward, models/csrc/msmv_sampling/msmv_sampling.cpp:302-497

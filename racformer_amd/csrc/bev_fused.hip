@@ -18,6 +18,7 @@
 // For B>1 the reference pairs value frame i=b*T+t with the locations of (t'=i/B, b'=i%B)
 // (bev_self_attention.py:185-188 vs :162,173, quirk Q2); reproduced as written.
 #include "rac_common.h"
+#include <stdlib.h>
 
 #define BEV_MAX_DEPTH 16
 #define BEV_TWO_PI 6.283185307179586f
@@ -39,6 +40,7 @@ struct BevArgs {
     int B, T, Q, heads, NP, D, P, H, W;
     int ld_off, ld_ray, ld_scale, ld_queue;  // row strides (floats): slices of one fused GEMM output
     int blocks_per_b;
+    int xcd_remap;           // 1: blocks that share an XCD (blockIdx & 7) take a contiguous range of items (speed only)
 };
 
 __device__ __forceinline__ void bev_keypoint(const BevArgs &a, int bq, int tq, int q, int h, int p, float *loc2)
@@ -99,7 +101,7 @@ __device__ __forceinline__ void bev_warp(const BevArgs &a, float px, float py, f
 }
 
 template <typename FT>
-__global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
+__global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs a)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x;
@@ -108,13 +110,21 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
     const int T = a.T, P = a.P, TP = a.T * a.P, D = a.D;
 
     const int per_b = a.Q * a.heads;
-    const int b = blockIdx.x / a.blocks_per_b;
-    const int i0 = (blockIdx.x % a.blocks_per_b) * BEV_GI;
+    int bid = blockIdx.x;
+    if (a.xcd_remap) {
+        // blocks id, id+8, id+16, ... run on one XCD (one 4 MiB L2): give them neighbouring queries -- neighbouring
+        // rays of the polar query grid sample neighbouring BEV pixels.  Bijective for any grid size.
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, x = bid & 7;
+        bid = (x < rr ? x * (qq + 1) : rr * (qq + 1) + (x - rr) * qq) + (bid >> 3);
+    }
+    const int b = bid / a.blocks_per_b;
+    const int i0 = (bid % a.blocks_per_b) * BEV_GI;
     const int nitems = min(BEV_GI, per_b - i0);
 
     float *sloc = smem;                        // [GI][T][P][2]
-    float *sattn = sloc + BEV_GI * TP * 2;     // [GI][P]
-    float *sq = sattn + BEV_GI * P;            // [GI][T]
+    const int Tw = a.B > 1 ? T : 1;            // B > 1: the point weights depend on the frame (paired batch, quirk Q2)
+    float *sattn = sloc + BEV_GI * TP * 2;     // [GI][Tw][P]
+    float *sq = sattn + BEV_GI * Tw * P;       // [GI][T]
     float *sbase = sq + BEV_GI * T;            // [GI][P][2]  T-invariant base points (B==1)
     float *sdoff = sbase + BEV_GI * P * 2;     // [GI][D]
     float *spart = sdoff + BEV_GI * BEV_MAX_DEPTH;  // [GI][TS][64] partial sums
@@ -179,6 +189,15 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
             const int fi = b * T + t;                // value frame index
             const int bq = fi % a.B, tq = fi / a.B;  // whose locations it is paired with (quirk Q2)
             bev_keypoint(a, bq, tq, q, h, p, sloc + i * 2);
+            // point softmax of the paired batch b' (rare path: every thread redoes the P-term reduction)
+            const float *lg = a.scale + ((size_t)bq * a.Q + q) * a.ld_scale + (size_t)h * P;
+            float wmax = lg[0];
+            for (int pj = 1; pj < P; ++pj)
+                wmax = fmaxf(wmax, lg[pj]);
+            float s2 = 0.f;
+            for (int pj = 0; pj < P; ++pj)
+                s2 += expf(lg[pj] - wmax);
+            sattn[(kk * T + t) * P + p] = expf(lg[p] - wmax) / s2;
         }
         if (a.loc_out) {
             float *lo = a.loc_out + (((((size_t)b * a.Q + q) * a.heads + h) * T + t) * P + p) * 2;
@@ -190,72 +209,52 @@ __global__ __launch_bounds__(256) void bev_sampling_d64_kernel(const BevArgs a)
 
     rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
     const bool live = k < nitems;
-    const int it = i0 + (live ? k : 0), q = it / a.heads, h = it % a.heads;
+    const int it = i0 + (live ? k : 0), h = it % a.heads;
     const int H = a.H, W = a.W, stride = a.heads * 64;
     const long keys = (long)H * W;
     if (live) {
-        // Every group walks ALL frames in the same order and owns the points p = ts, ts+4, ... of each: the whole
-        // chip then works on (nearly) one 16.8 MB frame at a time instead of four, which the L2s / Infinity Cache
-        // hold better (measured 91 -> 76 us against splitting the frames over the groups).
-        for (int t = 0; t < T; ++t) {
-            const int fi = b * T + t;
-            const FT *base = (const FT *)a.value + ((size_t)fi * keys * a.heads + h) * 64 + c4 * 4;
-            const float *lp = sloc + (k * TP + t * P) * 2;
-            const float *ap = sattn + k * P;
-            float wsum_inv = 1.f, wmax = 0.f;
-            const float *lg = nullptr;
-            if (a.B > 1) {  // recompute the point softmax from the paired batch b' (rare path)
-                const int bq = fi % a.B;
-                lg = a.scale + ((size_t)bq * a.Q + q) * a.ld_scale + (size_t)h * P;
-                wmax = lg[0];
-                for (int p = 1; p < P; ++p)
-                    wmax = fmaxf(wmax, lg[p]);
-                float s2 = 0.f;
-                for (int p = 0; p < P; ++p)
-                    s2 += expf(lg[p] - wmax);
-                wsum_inv = 1.f / s2;
-            }
-            rac_f4 at = {0.f, 0.f, 0.f, 0.f};
-            for (int p0 = ts; p0 < P; p0 += 4 * BEV_TS) {
-                rac_f4 v[4][4];
-                float tw[4][4];
+        // A group owns the points p = ts, ts+4, ... of every frame and walks its (frame, point) pairs frame-major, four
+        // at a time (16 taps in flight, every batch full): all groups move through the frames in the same order, so the
+        // chip works on (nearly) one 16.8 MB frame at a time, which the L2s / Infinity Cache hold better than four.
+        const int npp = (P - ts + BEV_TS - 1) / BEV_TS;   // this subset's points per frame
+        const int total = T * npp;
+        const float *qw = sq + k * T;
+        for (int j0 = 0; j0 < total; j0 += 4) {
+            rac_f4 v[4][4];
+            float tw[4][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int p = p0 + BEV_TS * u;
-                    const bool act = p < P;
-                    const int pp = act ? p : P - 1;
-                    const float x = lp[pp * 2], y = lp[pp * 2 + 1];
-                    float wgt = a.B > 1 ? expf(lg[pp] - wmax) * wsum_inv : ap[pp];
-                    wgt = act ? wgt : 0.f;
-                    const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
-                    const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                    const float hf = floorf(h_im), wf = floorf(w_im);
-                    const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                    const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
-                    const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-                    v[u][0] = bev_tap(base, (long)h_low * W + w_low, stride, t_ok && l_ok);
-                    v[u][1] = bev_tap(base, (long)h_low * W + w_high, stride, t_ok && r_ok);
-                    v[u][2] = bev_tap(base, (long)h_high * W + w_low, stride, b_ok && l_ok);
-                    v[u][3] = bev_tap(base, (long)h_high * W + w_high, stride, b_ok && r_ok);
-                    tw[u][0] = hh * hw * wgt;
-                    tw[u][1] = hh * lw * wgt;
-                    tw[u][2] = lh * hw * wgt;
-                    tw[u][3] = lh * lw * wgt;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    at.x += tw[u][0] * v[u][0].x + tw[u][1] * v[u][1].x + tw[u][2] * v[u][2].x + tw[u][3] * v[u][3].x;
-                    at.y += tw[u][0] * v[u][0].y + tw[u][1] * v[u][1].y + tw[u][2] * v[u][2].y + tw[u][3] * v[u][3].y;
-                    at.z += tw[u][0] * v[u][0].z + tw[u][1] * v[u][1].z + tw[u][2] * v[u][2].z + tw[u][3] * v[u][3].z;
-                    at.w += tw[u][0] * v[u][0].w + tw[u][1] * v[u][1].w + tw[u][2] * v[u][2].w + tw[u][3] * v[u][3].w;
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                const bool act = j < total;
+                const int jj = act ? j : total - 1;
+                const int t = jj / npp, p = ts + BEV_TS * (jj - t * npp);
+                const FT *base = (const FT *)a.value + ((size_t)(b * T + t) * keys * a.heads + h) * 64 + c4 * 4;
+                const float *lp = sloc + (k * TP + t * P + p) * 2;
+                const float x = lp[0], y = lp[1];
+                const float wgt = act ? sattn[(k * Tw + (a.B > 1 ? t : 0)) * P + p] * qw[t] : 0.f;
+                const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
+                const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
+                const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+                v[u][0] = bev_tap(base, (long)h_low * W + w_low, stride, t_ok && l_ok);
+                v[u][1] = bev_tap(base, (long)h_low * W + w_high, stride, t_ok && r_ok);
+                v[u][2] = bev_tap(base, (long)h_high * W + w_low, stride, b_ok && l_ok);
+                v[u][3] = bev_tap(base, (long)h_high * W + w_high, stride, b_ok && r_ok);
+                tw[u][0] = hh * hw * wgt;
+                tw[u][1] = hh * lw * wgt;
+                tw[u][2] = lh * hw * wgt;
+                tw[u][3] = lh * lw * wgt;
             }
-            const float fw = sq[k * T + t];
-            acc.x += at.x * fw;
-            acc.y += at.y * fw;
-            acc.z += at.z * fw;
-            acc.w += at.w * fw;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x += tw[u][0] * v[u][0].x + tw[u][1] * v[u][1].x + tw[u][2] * v[u][2].x + tw[u][3] * v[u][3].x;
+                acc.y += tw[u][0] * v[u][0].y + tw[u][1] * v[u][1].y + tw[u][2] * v[u][2].y + tw[u][3] * v[u][3].y;
+                acc.z += tw[u][0] * v[u][0].z + tw[u][1] * v[u][1].z + tw[u][2] * v[u][2].z + tw[u][3] * v[u][3].z;
+                acc.w += tw[u][0] * v[u][0].w + tw[u][1] * v[u][1].w + tw[u][2] * v[u][2].w + tw[u][3] * v[u][3].w;
+            }
         }
     }
     // phase D: fixed-order sum of the four point subsets (deterministic, no atomics)
@@ -285,7 +284,7 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
                   "rac_bev_sampling_fwd: bad sizes B=%d T=%d Q=%d heads=%d NP=%d D=%d H=%d W=%d", B, T, Q, heads, NP, D, H, W);
     RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_bev_sampling_fwd: dtype %d", dtype);
     const int P = NP * D;
-    const size_t lds = ((size_t)BEV_GI * T * P * 2 + (size_t)BEV_GI * P + (size_t)BEV_GI * T + (size_t)BEV_GI * P * 2 +
+    const size_t lds = ((size_t)BEV_GI * T * P * 2 + (size_t)BEV_GI * (B > 1 ? T : 1) * P + (size_t)BEV_GI * T + (size_t)BEV_GI * P * 2 +
                         (size_t)BEV_GI * BEV_MAX_DEPTH + (size_t)BEV_GI * BEV_TS * 64) * sizeof(float);
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_bev_sampling_fwd: T*P=%d too large for the LDS staging", T * P);
     if (B == 0 || Q == 0)
@@ -306,6 +305,8 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
     a.B = B; a.T = T; a.Q = Q; a.heads = heads; a.NP = NP; a.D = D; a.P = P; a.H = H; a.W = W;
     a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale; a.ld_queue = ld_queue;
     a.blocks_per_b = (Q * heads + BEV_GI - 1) / BEV_GI;
+    static const int xcd_remap = getenv("RAC_BEV_XCD_REMAP") ? atoi(getenv("RAC_BEV_XCD_REMAP")) : 1;
+    a.xcd_remap = xcd_remap;
     const int nb = B * a.blocks_per_b;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RAC_F32)

@@ -385,3 +385,29 @@ def conv3x3_fused(sources, ws, w_alpha, bias):
     if ev:
         ev[1].record()
     return out
+
+
+# ------------------------------------------------------------------------------------------- temporal encoder pieces
+def gru_gate_fused(gates, h_prev, h_out):
+    """ConvGRUCell's element-wise update, one launch: gates [B,3C,H,W] contiguous; h_prev / h_out [B,C,H,W] views whose
+    per-batch blocks are contiguous (e.g. the [:, t] slot of a [B,T,C,H,W] tensor).  Writes h_out."""
+    B, C3, H, W = gates.shape
+    C = C3 // 3
+    for t in (h_prev, h_out):
+        if not t.is_cuda or tuple(t.shape) != (B, C, H, W) or t[0].is_contiguous() is False or t.dtype != torch.float32:
+            raise RuntimeError("gru_gate_fused: h_prev / h_out must be float32 CUDA [B,C,H,W] views with contiguous batches")
+    _lib.require_gpu(gates, what="gru_gate_fused")
+    rc = _lib.lib().rac_gru_gate_fwd(_lib.ptr(gates), _lib.ptr(h_prev), h_prev.stride(0) if B > 1 else C * H * W, _lib.ptr(h_out),
+                                     h_out.stride(0) if B > 1 else C * H * W, B, C, H * W, _lib.stream_ptr())
+    _lib.check(rc, "rac_gru_gate_fwd")
+    return h_out
+
+
+def upsample2x_fused(x):
+    """nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) on a contiguous [N,C,h,w] tensor, one launch."""
+    _lib.require_gpu(x, what="upsample2x_fused")
+    N, C, h, w = x.shape
+    out = torch.empty(N, C, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().rac_upsample2x_fwd(_lib.ptr(x), _lib.ptr(out), N * C, h, w, _lib.stream_ptr())
+    _lib.check(rc, "rac_upsample2x_fwd")
+    return out

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_SLICE, conv3x3_fused, pack_conv3x3_weight, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_SLICE, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
                     pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
 from .msda import msda_forward
 from .msmv import msmv_forward
@@ -263,8 +263,11 @@ class ConvGRUCell(nn.Module):
                                     kernel_size=kernel_size, padding=kernel_size // 2)
         self.matching_layer = nn.Conv2d(hidden_channels, input_channels, 1)
 
+    def gates(self, x, h_prev):
+        return self.gates_conv(torch.cat([x, self.matching_layer(h_prev)], dim=1))
+
     def forward(self, x, h_prev):
-        gates = self.gates_conv(torch.cat([x, self.matching_layer(h_prev)], dim=1))
+        gates = self.gates(x, h_prev)
         z_gate, r_gate, cand = torch.split(gates, self.hidden_channels, dim=1)
         z, r = torch.sigmoid(z_gate), torch.sigmoid(r_gate)
         cand = torch.tanh(cand + r * h_prev)
@@ -283,9 +286,15 @@ class ConvGRU(nn.Module):
         B, T, C, H, W = x.shape
         h = torch.zeros(B, self.hidden_channels, H, W, device=x.device, dtype=x.dtype)
         out = torch.zeros(B, T, self.hidden_channels, H, W, device=x.device, dtype=x.dtype)
+        fused = x.is_cuda and x.dtype == torch.float32 and (self.hidden_channels * H * W) % 4 == 0
         for t in range(min(4, T)):
-            h = self.convGRUCell(x[:, t], h)
-            out[:, t] = h
+            if fused:
+                # gates convolution (MIOpen), then the whole element-wise update in one launch, written straight into
+                # the step's output slot (which is the next step's hidden state)
+                h = gru_gate_fused(self.convGRUCell.gates(x[:, t], h), h, out[:, t])
+            else:
+                h = self.convGRUCell(x[:, t], h)
+                out[:, t] = h
         return out
 
 
@@ -312,7 +321,19 @@ class RadarBEVTemporalEncoder(nn.Module):
         r = self.downsample_ratio
         x = bev_feats.flatten(0, 1)   # NCHW: an NHWC (channels_last) pipeline measured 3 % slower end to end
         down = self.downsample(x).reshape(B, T, self.hidden_dims, H // r, W // r)
-        return x, self.upsample(self.convGRU(down).flatten(0, 1))
+        gru = self.convGRU(down)
+        Tv = min(4, T)
+        if not (x.is_cuda and x.dtype == torch.float32 and r == 2 and Tv < T):
+            return x, self.upsample(gru.flatten(0, 1))
+        # ConvGRU leaves the frames t >= 4 at zero (:674-693): their upsample is zero and the 3x3 convolution of an
+        # all-zero map is exactly its bias, so only the first frames go through the resize (one HIP launch instead
+        # of torch's generic kernel) and the convolution.
+        conv = self.upsample[1]
+        hv = conv(upsample2x_fused(gru[:, :Tv].reshape(B * Tv, self.hidden_dims, H // r, W // r)))
+        hid = torch.empty(B, T, self.hidden_dims, H, W, device=x.device, dtype=x.dtype)
+        hid[:, :Tv] = hv.view(B, Tv, self.hidden_dims, H, W)
+        hid[:, Tv:] = (conv.bias if conv.bias is not None else hv.new_zeros(self.hidden_dims)).view(1, 1, -1, 1, 1)
+        return x, hid.flatten(0, 1)
 
     def forward(self, bev_feats):
         B, T, C, H, W = bev_feats.shape

@@ -291,3 +291,28 @@ def test_conv3x3_fused_matches_fp32_conv(shape):
         scale = want.abs().max().item()
         err = (got.double().cpu() - want).abs().max().item()
         assert err <= tol * scale, (shape, mag, err, scale)
+
+
+def test_temporal_encoder_fused_pieces():
+    """rac_gru_gate_fwd / rac_upsample2x_fwd against the torch formulation, and the whole RadarBEVTemporalEncoder
+    (fused convolution + fused pieces, channel-last output) against the reference decomposition (oracle on CPU)."""
+    from racformer_amd.fused import gru_gate_fused, pack_conv3x3_weight, upsample2x_fused
+    from racformer_amd.transformer import ConvGRUCell, RadarBEVTemporalEncoder
+    torch.manual_seed(9)
+    x = torch.randn(3, 8, 20, 12, device=DEV)
+    want = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    assert (upsample2x_fused(x) - want).abs().max().item() < 1e-5      # 4-term blends of O(1) values, fma contraction differs
+    cell = ConvGRUCell(16, 16, 3).to(DEV)
+    xs, h0 = torch.randn(2, 16, 8, 8, device=DEV), torch.randn(2, 3, 16, 8, 8, device=DEV)
+    with torch.no_grad():
+        want = cell(xs, h0[:, 1])
+        out = torch.zeros(2, 3, 16, 8, 8, device=DEV)
+        gru_gate_fused(cell.gates(xs, h0[:, 1]), h0[:, 1], out[:, 2])
+    assert (out[:, 2] - want).abs().max().item() < 2e-6 and float(out[:, :2].abs().max()) == 0.0
+    enc = RadarBEVTemporalEncoder(256, 64, 8).eval()
+    bev = torch.randn(1, 8, 256, 16, 16) * 0.5
+    with torch.no_grad():
+        ref = enc(bev)                                                     # CPU: the reference decomposition
+        eg = enc.to(DEV)
+        got = eg.forward_channel_last(bev.to(DEV), pack_conv3x3_weight(eg.temporal_fusion.weight))
+    assert (got.permute(0, 3, 1, 2).cpu() - ref[0]).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5

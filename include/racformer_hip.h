@@ -32,6 +32,7 @@
  *                        models/racformer_transformer.py:589-603
  *   rac_sasa_fwd      <- ScaleAdaptiveSelfAttention.inner_forward's mask + attention product
  *                        models/racformer_transformer.py:296-335
+ *   rac_rowgemm_fwd   <- nn.Linear + its preceding add / LayerNorm / ReLU groups, models/racformer_transformer.py:170-177, 243-269
  *   rac_gru_gate_fwd / rac_upsample2x_fwd <- ConvGRUCell.forward's element-wise tail, nn.Upsample
  *                        models/racformer_transformer.py:705-720, :633-636
  *   rac_absmax_fwd / rac_conv_pack_fwd / rac_conv3x3_fwd <- RadarBEVTemporalEncoder.temporal_fusion (nn.Conv2d 3x3)
@@ -215,8 +216,9 @@ int rac_mixing_fwd(const float *x, const float *params, float param_scale, float
 /* The temporal-fusion convolution of RadarBEVTemporalEncoder (3x3, stride 1, pad 1, Cin -> 256; the 193-GFLOP
  * nn.Conv2d of models/racformer_transformer.py:631,655) as an implicit GEMM on the f16 matrix cores with
  * hi/lo-split operands (3 products, fp32 accumulate: fp32-convolution accuracy).  Three calls:
- *   rac_absmax_fwd    amax_out[0] = max |v| over `num` device arrays (srcs / counts: HOST arrays; 16-byte aligned
- *                     sources); enqueues a memset of amax_out first.  Fixes the activations' power-of-two scale.
+ *   rac_absmax_fwd    amax_out[0] = max(floor_value, max |v| over `num` device arrays) (srcs / counts: HOST arrays;
+ *                     16-byte aligned sources); enqueues a 4-byte memset of amax_out first.  Fixes the activations'
+ *                     power-of-two scale; floor_value >= 0 covers sources whose bound is known without reading them.
  *   rac_conv_pack_fwd src [N,C,H,W] f32 -> channel range [c_offset, c_offset+C) of the kernel's activation image
  *                     xs = f16 [N][H+2][W+2][c_total/32][2][32] (per pixel and 32-channel chunk: hi, then lo, of
  *                     v * 2^e; e from *amax).  Only interior pixels are written: the caller zeroes xs once (border =
@@ -224,7 +226,8 @@ int rac_mixing_fwd(const float *x, const float *params, float param_scale, float
  *   rac_conv3x3_fwd   out [N,H,W,256] f32 (channel-last) = conv3x3(xs) * w_alpha / 2^e + bias, with
  *                     ws = f16 [9 taps (ky*3+kx)][Cin/32][256][2][32] holding hi / lo of weight[co][ci][ky][kx] / w_alpha
  *                     (w_alpha a power of two chosen by the packer).  H*W must be a multiple of 256. */
-int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float *amax_out, void *stream);
+int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float floor_value, float *amax_out,
+                   void *stream);
 int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, int N, int C, int H, int W, int c_total,
                       int c_offset, void *stream);
 int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
@@ -239,6 +242,32 @@ int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const flo
 int rac_gru_gate_fwd(const float *gates, const float *h_prev, int64_t h_prev_bstride, float *h_out, int64_t h_out_bstride,
                      int B, int C, int HW, void *stream);
 int rac_upsample2x_fwd(const float *src, float *dst, int64_t planes, int h, int w, void *stream);
+
+/* The small dense layers of a decoder layer with their surrounding row-wise work in one launch
+ * (models/racformer_transformer.py:170-177, 243-269: nn.Linear + the add / split-K sum / nn.LayerNorm / ReLU before it):
+ *   X   = per 256-wide segment s:  [relu]( LN( a_scale * sum_p a[p] + bias0 + residual ) * gamma + beta ) [+ post]
+ *   out = [relu on columns >= relu_from]( X @ w^T + b ),   w [N][256*num_seg] (torch Linear layout), exact-fp32 MFMA.
+ * Segment sources are rows of 256 floats: row r of partial p at a + p*partial_stride + r*ld_a; residual / post / x_out
+ * rows at their own strides; gamma == NULL skips the LayerNorm (relu / post still apply).  x_out (optional) receives
+ * the finished segment; split_out (optional) its f16 [hi | hi | lo | pad] image (layout of rac_add_ln_fwd's split_out).
+ * Up to RAC_ROWGEMM_MAX_BATCH independent GEMMs over the same `rows` share the launch (descs: HOST array). */
+#define RAC_ROWGEMM_MAX_BATCH 3
+typedef struct {
+    const float *a;
+    int64_t partial_stride;
+    const float *bias0, *residual, *gamma, *beta, *post;
+    float *x_out;
+    void *split_out;
+    int ld_a, num_partials, ld_res, ld_post, ld_xout, relu, split_pad;
+    float a_scale, eps, split_scale;
+} rac_rowseg;
+typedef struct {
+    rac_rowseg seg[3];
+    const float *w, *b;
+    float *out;
+    int num_seg, N, ld_out, relu_from;
+} rac_rowgemm;
+int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream);
 
 /* Backward of the two gather operators (SURVEY.md section 8 "next" row f4; fp32 features only).
  * rac_msmv_bwd  <- _ms_deform_attn_cuda_{c45,c2345,c23456}_backward, models/csrc/msmv_sampling/msmv_sampling.cpp:302-497

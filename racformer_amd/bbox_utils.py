@@ -8,14 +8,26 @@ import math
 import torch
 
 _TWO_PI = 2 * math.pi
+_CONSTS = {}
+
+
+def const_tensor(like, values):
+    """Small constant vector on ``like``'s device / dtype, uploaded once.  (``like.new_tensor(list)`` is a
+    blocking pageable host-to-device copy: on the GPU it stalls the host until the stream has drained, once per
+    call, and cannot be captured in a HIP graph.)"""
+    key = (str(like.device), like.dtype, tuple(float(v) for v in values))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(list(key[2]), device=like.device, dtype=like.dtype)
+    return t
 
 
 def decode_bbox(bboxes, pc_range=None):
     """bbox/utils.py:66-80 -> [x, y, z, w, l, h, yaw, (vx, vy)]"""
     xyz = bboxes[..., 0:3]
     if pc_range is not None:
-        lo = bboxes.new_tensor(pc_range[0:3])
-        span = bboxes.new_tensor([pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]])
+        lo = const_tensor(bboxes, pc_range[0:3])
+        span = const_tensor(bboxes, [pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]])
         xyz = xyz * span + lo
     parts = [xyz, bboxes[..., 3:6].exp(), torch.atan2(bboxes[..., 6:7], bboxes[..., 7:8])]
     if bboxes.shape[-1] > 8:

@@ -20,6 +20,7 @@
 // step k and written after them; one barrier per step), fragments are 16-byte LDS reads made conflict-free by an
 // XOR swizzle of the 16-byte slots (slot ^ ((row >> 1) & 7)), 96 MFMAs per wave and step.
 #include "rac_common.h"
+#include <string.h>
 
 typedef _Float16 cv_h8 __attribute__((ext_vector_type(8)));
 typedef float cv_f4 __attribute__((ext_vector_type(4)));
@@ -218,10 +219,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI
-extern "C" int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float *amax_out, void *stream)
+extern "C" int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float floor_value, float *amax_out,
+                              void *stream)
 {
-    RAC_CHECK_ARG(num >= 0 && amax_out, "rac_absmax_fwd: bad arguments");
-    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
+    RAC_CHECK_ARG(num >= 0 && amax_out && floor_value >= 0.f, "rac_absmax_fwd: bad arguments");
+    unsigned floor_bits;
+    memcpy(&floor_bits, &floor_value, sizeof(floor_bits));
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)amax_out, (int)floor_bits, 1, (hipStream_t)stream);
     if (e != hipSuccess) {
         rac_set_error("rac_absmax_fwd: %s", hipGetErrorString(e));
         return (int)e;

@@ -351,10 +351,11 @@ def pack_conv3x3_weight(weight):
 _conv_images = {}
 
 
-def conv3x3_fused(sources, ws, w_alpha, bias):
+def conv3x3_fused(sources, ws, w_alpha, bias, bounds=None):
     """3x3 / stride 1 / pad 1 convolution of the channel concatenation of ``sources`` (NCHW fp32 tensors with
     equal N, H, W) -> [N, H, W, 256] fp32 channel-last.  absmax -> pack (NCHW fp32 -> padded channel-last f16
-    hi/lo image) -> implicit-GEMM kernel; the padded image buffer is allocated (zeroed) once per shape."""
+    hi/lo image) -> implicit-GEMM kernel; the padded image buffer is allocated (zeroed) once per shape.
+    ``bounds[i]``: a known upper bound of |sources[i]| (the source is then not scanned by the absmax pass)."""
     _lib.require_gpu(*sources, ws, what="conv3x3_fused")
     N, _, H, W = sources[0].shape
     cin = sum(int(t.shape[1]) for t in sources)
@@ -364,14 +365,17 @@ def conv3x3_fused(sources, ws, w_alpha, bias):
     if xs is None:
         xs = _conv_images[key] = torch.zeros(N, H + 2, W + 2, cin // 32, 2, 32, device=dev, dtype=torch.float16)
     amax = torch.empty(1, device=dev, dtype=torch.float32)
-    n = len(sources)
-    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in sources])
-    counts = (ctypes.c_int64 * n)(*[t.numel() for t in sources])
+    bounds = list(bounds) if bounds is not None else [None] * len(sources)
+    scan = [t for t, bnd in zip(sources, bounds) if bnd is None]
+    floor = max([0.0] + [float(bnd) for bnd in bounds if bnd is not None])
+    n = len(scan)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in scan])
+    counts = (ctypes.c_int64 * max(n, 1))(*[t.numel() for t in scan])
     L = _lib.lib()
     ev = _lib.timer.record("temporal_fusion_conv") if _lib.timer is not None else None
     if ev:
         ev[0].record()
-    _lib.check(L.rac_absmax_fwd(ptrs, counts, n, _lib.ptr(amax), _lib.stream_ptr()), "rac_absmax_fwd")
+    _lib.check(L.rac_absmax_fwd(ptrs, counts, n, floor, _lib.ptr(amax), _lib.stream_ptr()), "rac_absmax_fwd")
     off = 0
     for t in sources:
         if tuple(t.shape[0:1] + t.shape[2:]) != (N, H, W) or t.dtype != torch.float32:
@@ -411,3 +415,88 @@ def upsample2x_fused(x):
     rc = _lib.lib().rac_upsample2x_fwd(_lib.ptr(x), _lib.ptr(out), N * C, h, w, _lib.stream_ptr())
     _lib.check(rc, "rac_upsample2x_fwd")
     return out
+
+
+# ------------------------------------------------------------------------------------------- row GEMMs
+def _rows2d(t, what):
+    """-> (tensor kept alive, pointer, row stride) of a float32 CUDA [rows, W] / [B, Q, W] view with unit inner stride."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1:
+        raise RuntimeError(f"racformer_amd.rowgemm({what}): expected a float32 CUDA tensor with unit inner stride")
+    if t.dim() == 3:
+        if t.stride(0) != t.shape[1] * t.stride(1):
+            raise RuntimeError(f"racformer_amd.rowgemm({what}): rows must be equally strided")
+        ld = t.stride(1)
+    elif t.dim() == 2:
+        ld = t.stride(0)
+    else:
+        raise RuntimeError(f"racformer_amd.rowgemm({what}): expected [rows, W] or [B, Q, W]")
+    return t, ctypes.c_void_p(t.data_ptr()), int(ld)
+
+
+def row_seg(a, num_partials=1, a_scale=1.0, bias0=None, residual=None, norm=None, relu=False, post=None, x_out=None,
+            split_out=None):
+    """One 256-wide segment of a rowgemm's A operand (see rac_rowgemm_fwd):
+    [relu](LN_norm(a_scale * sum_p a[p] + bias0 + residual)) [+ post]; ``a`` is [rows,256] (any row stride) or, with
+    num_partials = S > 1, a contiguous [S, rows, 256].  ``x_out`` / ``split_out``: destinations for the finished rows
+    (fp32 [rows,256] / f16 [rows, 768 + SPLIT_BIAS_PAD])."""
+    g = _lib.RowSeg()
+    keep = []
+    if num_partials > 1:
+        if not a.is_contiguous() or a.shape[0] != num_partials or a.shape[-1] != 256:
+            raise RuntimeError("row_seg: partials must be a contiguous [S, rows, 256] tensor")
+        g.a, g.ld_a, g.partial_stride = ctypes.c_void_p(a.data_ptr()), 256, a.numel() // num_partials
+        keep.append(a)
+    else:
+        if a.shape[-1] != 256:
+            raise RuntimeError("row_seg: segments are 256 wide")
+        t, g.a, g.ld_a = _rows2d(a, "a")
+        g.partial_stride = 0
+        keep.append(t)
+    g.num_partials, g.a_scale, g.relu = num_partials, float(a_scale), int(relu)
+    if bias0 is not None:
+        g.bias0 = ctypes.c_void_p(bias0.data_ptr())
+        keep.append(bias0)
+    if residual is not None:
+        t, g.residual, g.ld_res = _rows2d(residual, "residual")
+        keep.append(t)
+    if norm is not None:
+        g.gamma, g.beta, g.eps = ctypes.c_void_p(norm.weight.data_ptr()), ctypes.c_void_p(norm.bias.data_ptr()), float(norm.eps)
+    if post is not None:
+        t, g.post, g.ld_post = _rows2d(post, "post")
+        keep.append(t)
+    if x_out is not None:
+        t, g.x_out, g.ld_xout = _rows2d(x_out, "x_out")
+        keep.append(t)
+    if split_out is not None:
+        if split_out.dtype != torch.float16 or not split_out.is_contiguous() or split_out.shape[-1] != 768 + SPLIT_BIAS_PAD:
+            raise RuntimeError("row_seg: split_out must be a contiguous f16 [rows, 768 + SPLIT_BIAS_PAD] tensor")
+        g.split_out, g.split_scale, g.split_pad = ctypes.c_void_p(split_out.data_ptr()), SPLIT_ACT_SCALE, SPLIT_BIAS_PAD
+        keep.append(split_out)
+    g._keep = keep
+    return g
+
+
+def row_gemm(segs, weight, bias, out, relu_from=None):
+    """out = [relu on columns >= relu_from](cat(segs) @ weight.T + bias); weight [N, 256*len(segs)] contiguous."""
+    d = _lib.RowGemm()
+    N, K = weight.shape
+    if K != 256 * len(segs) or not weight.is_contiguous() or not weight.is_cuda or weight.dtype != torch.float32:
+        raise RuntimeError("row_gemm: weight must be a contiguous float32 CUDA [N, 256 * segments] tensor")
+    for i, g in enumerate(segs):
+        d.seg[i] = g
+    d.num_seg, d.N = len(segs), N
+    d.w = ctypes.c_void_p(weight.data_ptr())
+    d.b = ctypes.c_void_p(bias.data_ptr()) if bias is not None else None
+    t, d.out, d.ld_out = _rows2d(out, "out")
+    if out.shape[-1] != N:
+        raise RuntimeError("row_gemm: out must be [rows, N]")
+    d.relu_from = N if relu_from is None else int(relu_from)
+    d._keep = [segs, weight, bias, t]
+    return d
+
+
+def rowgemm_launch(descs, rows):
+    """One launch for up to 3 independent row GEMMs over the same rows."""
+    arr = (_lib.RowGemm * len(descs))(*descs)
+    rc = _lib.lib().rac_rowgemm_fwd(arr, len(descs), int(rows), _lib.stream_ptr())
+    _lib.check(rc, "rac_rowgemm_fwd")

@@ -6,7 +6,7 @@ Training-only parts (query denoising, losses, assigners) are out of scope (SURVE
 import torch
 import torch.nn as nn
 
-from .bbox_utils import denormalize_bbox
+from .bbox_utils import const_tensor, denormalize_bbox
 from .transformer import RaCFormerTransformer
 
 
@@ -28,7 +28,7 @@ class NMSFreeCoder:
         if self.post_center_range is None:
             raise NotImplementedError("Need to reorganize output as a batch, only support "
                                       "post_center_range is not None for now!")
-        limit = boxes.new_tensor(self.post_center_range)
+        limit = const_tensor(boxes, self.post_center_range)
         keep = (boxes[..., :3] >= limit[:3]).all(1) & (boxes[..., :3] <= limit[3:]).all(1)
         if self.score_threshold:
             keep &= scores > self.score_threshold
@@ -104,8 +104,8 @@ class RaCFormer_head(nn.Module):
         cls_scores, bbox_preds = self.transformer(query_bbox, query_feat, mlvl_feats, lss_bev_feats,
                                                   radar_bev_feats, attn_mask=None, img_metas=img_metas)
         pc = self.pc_range
-        lo = bbox_preds.new_tensor(pc[0:3])
-        span = bbox_preds.new_tensor([pc[3] - pc[0], pc[4] - pc[1], pc[5] - pc[2]])
+        lo = const_tensor(bbox_preds, pc[0:3])
+        span = const_tensor(bbox_preds, [pc[3] - pc[0], pc[4] - pc[1], pc[5] - pc[2]])
         xyz = bbox_preds[..., 0:3] * span + lo
         bbox_preds = torch.cat([xyz[..., 0:2], bbox_preds[..., 3:5], xyz[..., 2:3], bbox_preds[..., 5:10]], dim=-1)
         return {"all_cls_scores": cls_scores, "all_bbox_preds": bbox_preds, "enc_cls_scores": None,

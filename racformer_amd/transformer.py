@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_SLICE, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, row_gemm, row_seg, rowgemm_launch, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
                     pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
 from .msda import msda_forward
 from .msmv import msmv_forward
@@ -346,6 +346,12 @@ class RadarBEVTemporalEncoder(nn.Module):
     # output already channel-last for value_proj.
     fused_conv = True
 
+    def hidden_bound(self):
+        """Upper bound of |hidden_stream(.)[1]| from the weights of the last convolution (inputs bounded by 1)."""
+        conv = self.upsample[1]
+        bound = float(conv.weight.detach().abs().sum(dim=(1, 2, 3)).max())
+        return bound + (float(conv.bias.detach().abs().max()) if conv.bias is not None else 0.0)
+
     def fused_conv_supported(self, bev_feats):
         B, T, C, H, W = bev_feats.shape
         return (self.fused_conv and bev_feats.is_cuda and bev_feats.dtype == torch.float32 and self.embed_dims == 256
@@ -355,7 +361,10 @@ class RadarBEVTemporalEncoder(nn.Module):
     def forward_channel_last(self, bev_feats, packed):
         """-> [B*T, H, W, C] (channel-last).  ``packed`` = pack_conv3x3_weight(temporal_fusion.weight)."""
         x, hid = self.hidden_stream(bev_feats)
-        return conv3x3_fused([x.contiguous(), hid.contiguous()], packed[0], packed[1], self.temporal_fusion.bias)
+        # |ConvGRU state| <= 1 (convex combinations of tanh values, zero start), bilinear resizing keeps that, so
+        # |hid| <= max_row ||W_up||_1 + max|b_up|: known from the weights, no need to scan the tensor
+        return conv3x3_fused([x.contiguous(), hid.contiguous()], packed[0], packed[1], self.temporal_fusion.bias,
+                             bounds=[None, packed[2]])
 
 
 class BEVSelfAttention(nn.Module):
@@ -699,6 +708,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         self.overlap = False
         # The mixing generator and out_proj as split-precision f16-MFMA GEMMs (AdaptiveMixing.split_packs).  False: fp32 rocBLAS.
         self.split_gemm = True
+        # The ~17 small Linears of the layer with the add / LayerNorm / ReLU before them as rac_rowgemm_fwd launches (the
+        # producer's normalisation runs as the prologue of its consumer GEMM): 21 launches per layer instead of ~50.
+        # False: library GEMMs + rac_add_ln_fwd launches (forward_fused_chain).
+        self.rowgemm = True
         self._pack_cache = {}
 
     def _cached(self, key, params, fn):
@@ -747,7 +760,9 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
     def prepare(self, lss_bev_feats, radar_bev_feats):
         """Layer-invariant tensors (computed once per forward)."""
         te = self.sampling_radar_bev.temporal_encoder
-        conv_pack = self._cached("conv_pack", [te.temporal_fusion.weight], lambda: pack_conv3x3_weight(te.temporal_fusion.weight)) \
+        up = te.upsample[1]
+        conv_pack = self._cached("conv_pack", [te.temporal_fusion.weight, up.weight] + ([up.bias] if up.bias is not None else []),
+                                 lambda: pack_conv3x3_weight(te.temporal_fusion.weight) + (te.hidden_bound(),)) \
             if radar_bev_feats.is_cuda and self.fused and te.fused_conv else None
         radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack)
         lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
@@ -780,6 +795,94 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
                        and self.embed_dims == 256 and self.code_size == 10 and self.num_classes <= 16 else {}))
 
     def forward_fused(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None):
+        """The layer as hand-written HIP kernels plus the three big library GEMMs of the mixing: every small Linear is
+        a rac_rowgemm_fwd launch whose prologue performs the residual add / split-K sum / LayerNorm / ReLU that
+        precedes it in the reference (racformer_transformer.py:239-279); same arithmetic, fp32 throughout."""
+        if not self.rowgemm or (self.tail_kernel and "tail" in prepared) or self.overlap:
+            return self.forward_fused_chain(query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages)
+        meta = img_metas[0]
+        time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
+        qb = query_bbox.contiguous()
+        B, Q, E = query_feat.shape
+        n = B * Q
+        dev = query_feat.device
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)   # noqa: E731
+        pe, p = self.position_encoder, self.self_attn.attention.attn
+        packs = prepared.get("split_packs")
+        # position encoder: relu(LN(Linear(3->256))) in one kernel, second Linear raw
+        h = pe_head(qb[..., :3], pe[0], pe[1])
+        y2 = new(n, E)
+        rowgemm_launch([row_gemm([row_seg(h)], pe[3].weight, pe[3].bias, y2)], n)
+        # x = query_feat + relu(LN(y2));  q|k|v|tau = x @ [in_proj; gen_tau]^T
+        x, lin = new(B, Q, E), new(B, Q, 3 * E + self.self_attn.num_heads)
+        rowgemm_launch([row_gemm([row_seg(y2, norm=pe[4], relu=True, post=query_feat.contiguous(), x_out=x)],
+                                 prepared["sasa_w"][0], prepared["sasa_w"][1], lin)], n)
+        table = box_prep(qb, self.pc_range)      # decode_bbox(theta_d2xy(.)) once for SASA and the 3 sampling kernels
+        o = sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], qb, self.self_attn.num_heads, self.pc_range, box_table=table)
+        attn = new(n, E)
+        rowgemm_launch([row_gemm([row_seg(o)], p.out_proj.weight, p.out_proj.bias, attn)], n)
+        # x1 = norm1(x + attn) (+ its f16 image for the generator GEMM);  the eleven Linears of the three sampling modules
+        x1 = new(B, Q, E)
+        x1_split = torch.empty(n, 3 * E + SPLIT_BIAS_PAD, device=dev, dtype=torch.float16) if packs else None
+        wide = new(B, Q, prepared["wide_w"].shape[0])
+        rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split)],
+                                 prepared["wide_w"], prepared["wide_b"], wide)], n)
+        lin = wide.split(prepared["wide_widths"], dim=-1)
+        rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
+        r_off, r_ray, r_sc, r_qu = lin[3:7]
+        l_off, l_ray, l_sc, l_qu = lin[7:11]
+        bev = new(2, B, Q, E)
+        bev_sampling_fused(prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff,
+                           rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region,
+                           box_table=table, out=bev[0])
+        bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
+                           lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
+                           box_table=table, out=bev[1])
+        sampled_feat = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=lin[0:3],
+                                     box_table=table)
+        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)
+        p_scale = packs["out_alpha"] if packs else 1.0
+        # both BEV output projections in one launch
+        proj = new(2, n, E)
+        ro, lo = rb.attention.output_proj, lb.attention.output_proj
+        rowgemm_launch([row_gemm([row_seg(bev[0])], ro.weight, ro.bias, proj[0]),
+                        row_gemm([row_seg(bev[1])], lo.weight, lo.bias, proj[1])], n)
+        # fusion Linear over [norm2(mixing) | norm_radar(radar) | norm_lss(lss)], each third normalised in the prologue
+        S = partials.shape[0]
+        f_raw = new(n, E)
+        rowgemm_launch([row_gemm([row_seg(partials, num_partials=S, a_scale=p_scale, bias0=self.mixing.out_proj.bias,
+                                          residual=x1, norm=self.norm2),
+                                  row_seg(proj[0], residual=x1, norm=self.norm_radar_bev),
+                                  row_seg(proj[1], residual=x1, norm=self.norm_lss_bev)],
+                                 self.fusion.weight, self.fusion.bias, f_raw)], n)
+        # FFN: f = norm_fusion(f_raw); h1 = relu(W1 f); ffn_lin = W2 h1; x3 = norm3(f + ffn_lin)
+        f, h1, ffn_lin = new(n, E), new(n, 2 * E), new(n, E)
+        w1, w2 = self.ffn.layers[0][0], self.ffn.layers[1]
+        if w1.weight.shape[0] != 2 * E:
+            raise RuntimeError("forward_fused: feedforward_channels must be 2 * embed_dims")
+        rowgemm_launch([row_gemm([row_seg(f_raw, norm=self.norm_fusion, x_out=f)], w1.weight, w1.bias, h1, relu_from=0)], n)
+        rowgemm_launch([row_gemm([row_seg(h1[:, :E]), row_seg(h1[:, E:])], w2.weight, w2.bias, ffn_lin)], n)
+        x3, c0r0 = new(B, Q, E), new(n, 2 * E)
+        rowgemm_launch([row_gemm([row_seg(ffn_lin, residual=f, norm=self.norm3, x_out=x3)], prepared["c0r0_w"],
+                                 prepared["c0r0_b"], c0r0, relu_from=E)], n)       # (ReLU only on the reg half)
+        # cls / reg branches side by side
+        cb, rg = self.cls_branch, self.reg_branch
+        c3, r2 = new(n, E), new(n, E)
+        rowgemm_launch([row_gemm([row_seg(c0r0[:, :E], norm=cb[1], relu=True)], cb[3].weight, cb[3].bias, c3),
+                        row_gemm([row_seg(c0r0[:, E:])], rg[2].weight, rg[2].bias, r2, relu_from=0)], n)
+        cls_score, delta = new(B, Q, self.num_classes), new(B, Q, self.code_size)
+        rowgemm_launch([row_gemm([row_seg(c3, norm=cb[4], relu=True)], cb[6].weight, cb[6].bias, cls_score),
+                        row_gemm([row_seg(r2)], rg[4].weight, rg[4].bias, delta)], n)
+        bbox_pred, bbox_xy = refine_fused(qb, delta, meta["time_diff_safe"], self.num_ray)
+        if stages is not None:
+            mixed = x1 + p_scale * partials.sum(0).view_as(x1) + self.mixing.out_proj.bias
+            stages.update(position_encoder=x - query_feat, self_attn=x + attn.view_as(x),
+                          sampling_radar_bev=proj[0].view_as(x1) + x1, sampling_lss_bev=proj[1].view_as(x1) + x1,
+                          sampling=sampled_feat, mixing=mixed, ffn=(f + ffn_lin).view_as(x1))
+        self.last_bbox_xy = bbox_xy
+        return x3, cls_score, bbox_pred
+
+    def forward_fused_chain(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None):
         """The layer as a chain of library GEMMs and hand-written HIP kernels only: every LayerNorm is fused
         with the add / split-K reduction / bias / ReLU around it (rac_add_ln_fwd), the box tail is one
         kernel (rac_refine_fwd).  Same arithmetic as ``forward`` (racformer_transformer.py:239-279)."""
@@ -972,6 +1075,17 @@ class RaCFormerTransformerDecoder(nn.Module):
         td_safe = td.copy()
         td_safe[td_safe < 1e-5] = 1.0
         l2i = np.asarray([m["lidar2img"] for m in img_metas]).astype(np.float32)
+        if device.type == "cuda":
+            # one pinned staging block, one asynchronous copy: a pageable .to(device) would block the host until the
+            # stream has drained, i.e. serialise this sample's launches behind the previous sample's kernels
+            flat = np.concatenate([td.ravel(), td_safe.ravel(), l2i.ravel()])
+            host = torch.from_numpy(flat).pin_memory()    # (the caching host allocator keeps the block until the copy has run)
+            dev = host.to(device, non_blocking=True)
+            n0, n1 = td.size, td.size + td_safe.size
+            img_metas[0]["time_diff"] = dev[:n0].view(td.shape)
+            img_metas[0]["time_diff_safe"] = dev[n0:n1].view(td_safe.shape)
+            img_metas[0]["lidar2img"] = dev[n1:].view(l2i.shape)
+            return
         img_metas[0]["time_diff"] = torch.from_numpy(td).to(device)
         img_metas[0]["time_diff_safe"] = torch.from_numpy(td_safe).to(device)
         img_metas[0]["lidar2img"] = torch.from_numpy(l2i).to(device)

@@ -314,5 +314,70 @@ def test_temporal_encoder_fused_pieces():
     with torch.no_grad():
         ref = enc(bev)                                                     # CPU: the reference decomposition
         eg = enc.to(DEV)
-        got = eg.forward_channel_last(bev.to(DEV), pack_conv3x3_weight(eg.temporal_fusion.weight))
+        got = eg.forward_channel_last(bev.to(DEV), pack_conv3x3_weight(eg.temporal_fusion.weight) + (eg.hidden_bound(),))
     assert (got.permute(0, 3, 1, 2).cpu() - ref[0]).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("rows", [900, 37])
+def test_rowgemm_kernel(rows):
+    """rac_rowgemm_fwd against torch: plain / LayerNorm / split-K-sum prologues, ReLU placement, K = 256..768,
+    N = 10 .. 2189, batched launches, strided sources, side outputs (x_out, f16 split image)."""
+    from racformer_amd.fused import SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, row_gemm, row_seg, rowgemm_launch
+    torch.manual_seed(rows)
+    g = lambda *s: torch.randn(*s, device=DEV)   # noqa: E731
+    ln = [torch.nn.LayerNorm(256).to(DEV) for _ in range(3)]
+    for m in ln:
+        torch.nn.init.normal_(m.weight)
+        torch.nn.init.normal_(m.bias)
+    # 1) three LN segments, one of them a scaled split-K sum with bias and residual; K = 768, N = 256
+    parts, res, b0 = g(16, rows, 256), g(rows, 256), g(256)
+    p1, p2 = g(rows, 256), g(rows, 512)
+    W, b, out = g(256, 768) * 0.05, g(256), torch.empty(rows, 256, device=DEV)
+    xo = torch.empty(rows, 256, device=DEV)
+    rowgemm_launch([row_gemm([row_seg(parts, num_partials=16, a_scale=0.25, bias0=b0, residual=res, norm=ln[0], x_out=xo),
+                              row_seg(p1, residual=res, norm=ln[1], relu=True), row_seg(p2[:, 256:], norm=ln[2], post=res)],
+                             W, b, out)], rows)
+    s0 = ln[0](0.25 * parts.sum(0) + b0 + res)
+    s1 = torch.relu(ln[1](p1 + res))
+    s2 = ln[2](p2[:, 256:]) + res
+    want = torch.cat([s0, s1, s2], 1).double() @ W.double().t() + b.double()
+    assert (xo - s0).abs().max().item() < 2e-5
+    assert (out.double() - want).abs().max().item() < 2e-4 * want.abs().max().item()
+    # 2) batched: N = 10 with LN+ReLU prologue, N = 2189 plain with ReLU from column 100, and the split image
+    W1, b1, o1 = g(10, 256), g(10), torch.empty(1, rows, 10, device=DEV)
+    W2, b2, o2 = g(2189, 256) * 0.1, g(2189), torch.empty(rows, 2189, device=DEV)
+    img = torch.empty(rows, 768 + SPLIT_BIAS_PAD, device=DEV, dtype=torch.float16)
+    rowgemm_launch([row_gemm([row_seg(p1, norm=ln[0], relu=True)], W1, b1, o1),
+                    row_gemm([row_seg(p2[:, :256], split_out=img)], W2, b2, o2, relu_from=100)], rows)
+    w1 = torch.relu(ln[0](p1)).double() @ W1.double().t() + b1.double()
+    w2 = p2[:, :256].double() @ W2.double().t() + b2.double()
+    w2[:, 100:] = torch.relu(w2[:, 100:])
+    assert (o1[0].double() - w1).abs().max().item() < 1e-4 * w1.abs().max().item()
+    assert (o2.double() - w2).abs().max().item() < 1e-4 * w2.abs().max().item()
+    hi, hi2, lo, pad = img.float().split([256, 256, 256, SPLIT_BIAS_PAD], dim=1)
+    assert torch.equal(hi, hi2) and float(pad[:, 2:].abs().max()) == 0.0 and torch.all(pad[:, :2] == SPLIT_ACT_SCALE)
+    assert ((hi.double() + lo.double()) / SPLIT_ACT_SCALE - p2[:, :256].double()).abs().max().item() < 2.0 ** -20 * 6
+    # 3) K = 512 as two strided segments
+    W3, o3 = g(256, 512) * 0.05, torch.empty(rows, 256, device=DEV)
+    rowgemm_launch([row_gemm([row_seg(p2[:, :256]), row_seg(p2[:, 256:])], W3, None, o3, relu_from=0)], rows)
+    w3 = torch.relu(p2.double() @ W3.double().t())
+    assert (o3.double() - w3).abs().max().item() < 1e-4 * w3.abs().max().item()
+
+
+@pytest.mark.parametrize("cfg", [syn.SMALL6, syn.F8])
+def test_rowgemm_decoder_matches_library_gemm_chain(cfg):
+    """Whole decoder with the small Linears as rac_rowgemm_fwd launches (default) vs library GEMMs + rac_add_ln_fwd."""
+    outs = {}
+    for rg in (True, False):
+        tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+        syn.fill_params(tr, 72)
+        tr.decoder.decoder_layer.rowgemm = rg
+        tr = tr.to(DEV)
+        qb, qf = syn.make_queries(cfg, 71)
+        with torch.no_grad():
+            outs[rg] = tr(qb.to(DEV), qf.to(DEV), [f.to(DEV) for f in syn.make_pyramid(cfg, 71)],
+                          syn.make_bev(cfg, 71, 0).to(DEV), syn.make_bev(cfg, 71, 1).to(DEV), None, syn.make_img_metas(cfg))
+    torch.cuda.synchronize()
+    from parity import decoder_parity
+    decoder_parity(outs[True][0], outs[True][1], outs[False][0].cpu(), outs[False][1].cpu(), what="rowgemm vs chain")
+    assert (outs[True][1][0] - outs[False][1][0]).abs().max().item() < 1e-4

@@ -46,6 +46,7 @@ def build_head(cfg, device, feature_dtype=torch.float32):
         # e^N(0,1)-sized boxes and random yaw in every query (see racformer_amd/synthetic.py)
         head.init_query_bbox.weight.copy_(syn.make_queries(cfg, 0)[0][0])
     head.transformer.decoder.feature_dtype = feature_dtype
+    head.transformer.decoder.overlap_prepare = os.environ.get("RAC_OVERLAP_PREPARE", "0") != "0"   # experiment switch
     return head.eval().to(device)
 
 

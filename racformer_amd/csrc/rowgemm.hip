@@ -11,11 +11,12 @@
 // stored (x_out: residuals / layer outputs needed elsewhere; split_out: the f16 hi/lo image for a split-precision
 // library GEMM).  Up to three independent GEMMs over the same rows share a launch (blockIdx.z).
 //
-// Workgroup = 16 rows x 64 output columns (grid 57 x N/64: all CUs busy at N = 256), 4 waves, one 16x16 tile per
-// wave.  The 16 x K activation tile is built in LDS by the prologue (one wave per row, 16-byte accesses, two-pass
+// Workgroup = 16 rows x 64 output columns (grid 57 x N/64: all CUs busy at N = 256; 64 rows for N >= 512), 4 waves, one
+// 16x16 tile per wave and 16 rows.  The 16 x K activation tile is built in LDS by the prologue (one wave per row, 16-byte accesses, two-pass
 // statistics in registers); the weights stream from L2 straight into MFMA operands (torch's [out][in] layout, one
 // 16-byte load feeds four k-steps); arithmetic is v_mfma_f32_16x16x4_f32 -- exact fp32, bit-for-bit an fmaf chain.
 #include "rac_common.h"
+#include <stdlib.h>
 
 typedef float rg_f4 __attribute__((ext_vector_type(4)));
 
@@ -32,15 +33,30 @@ __device__ __forceinline__ float rg_wave_sum(float v)
     return v;
 }
 
-template <int NSEG>
+// NSEG: 256-wide segments of K.  MT: 16-row tiles per workgroup (1: 16 rows, all CUs busy at N = 256; 4: 64 rows, the
+// weight fragments of a wave are reused by four row tiles -- a quarter of the L2 weight traffic, for the wide layers).
+template <int NSEG, int MT>
 __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, float *sX)
 {
-    constexpr int K = 256 * NSEG, LD = K + 4;
+    constexpr int K = 256 * NSEG, LD = K + 4, R = 16 * MT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
+    const int row0 = blockIdx.x * R, n0 = blockIdx.y * 64;
     const bool first_slice = blockIdx.y == 0;
+    // GEMM roles (wave w owns columns n0 + 16w .. +15; lane (li, lk): A row li, B column li, k = 16u + 4lk + i).  The
+    // first segment's weights do not depend on the prologue: their 16 loads per lane are issued before it.  Row tiles
+    // of one column slice read the same weights: each starts at a different k-block (rot) so that they do not hit the
+    // same L2 lines in lock step (k is only a summation index).
+    const int li = lane & 15, lk = lane >> 4;
+    const int col = n0 + 16 * wave + li;
+    const int wrow = col < d.N ? col : d.N - 1;
+    const float *bp = d.w + (size_t)wrow * K + 4 * lk;
+    const int rot = (blockIdx.x * 5) & 15;
+    rac_f4 bcur[16], bnxt[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        bcur[u] = rac_ld4(bp + 16 * ((u + rot) & 15));
 
-    // ---- prologue: build the 16 x K activation tile (wave w: rows 4w..4w+3, lane: 4 columns of each segment) ----
+    // ---- prologue: build the R x K activation tile (wave w: rows w*R/4 .., 4 at a time; lane: 4 columns per segment) ----
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         const rac_rowseg &g = d.seg[s];
@@ -51,102 +67,141 @@ __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, flo
         }
         if (g.bias0)
             b0 = rac_ld4(g.bias0 + lane * 4);
+#pragma unroll 1
+        for (int rb = 0; rb < MT; ++rb) {
+            const int rbase = (wave * MT + rb) * 4;   // first of this pass's 4 rows within the tile
+            // sources first, four rows at once (and split-K partials two at a time): up to 8 independent 16-byte
+            // loads in flight per lane instead of one dependent load per row and partial
+            rac_f4 vv[4], rs[4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * wave + rr, row = row0 + r;
-            rac_f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < rows) {
-                const float *ap = g.a + (size_t)row * g.ld_a + lane * 4;
-                v = rac_ld4(ap);
-                for (int p = 1; p < g.num_partials; ++p) {
-                    const rac_f4 w = rac_ld4(ap + (size_t)p * g.partial_stride);
-                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-                }
-                v.x = v.x * g.a_scale + b0.x; v.y = v.y * g.a_scale + b0.y;
-                v.z = v.z * g.a_scale + b0.z; v.w = v.w * g.a_scale + b0.w;
-                if (g.residual) {
-                    const rac_f4 w = rac_ld4(g.residual + (size_t)row * g.ld_res + lane * 4);
-                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = row0 + rbase + rr;
+                vv[rr] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+                rs[rr] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+                if (row < rows) {
+                    vv[rr] = rac_ld4(g.a + (size_t)row * g.ld_a + lane * 4);
+                    if (g.residual)
+                        rs[rr] = rac_ld4(g.residual + (size_t)row * g.ld_res + lane * 4);
                 }
             }
-            if (g.gamma) {
-                const float mean = rg_wave_sum((v.x + v.y) + (v.z + v.w)) / 256.f;
-                const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-                const float rstd = 1.f / sqrtf(rg_wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 256.f + g.eps);
-                v.x = d0 * rstd * gm.x + bt.x; v.y = d1 * rstd * gm.y + bt.y;
-                v.z = d2 * rstd * gm.z + bt.z; v.w = d3 * rstd * gm.w + bt.w;
+            for (int p = 1; p < g.num_partials; p += 2) {
+                rac_f4 w[2][4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int row = row0 + rbase + rr;
+                        w[j][rr] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+                        if (row < rows && p + j < g.num_partials)
+                            w[j][rr] = rac_ld4(g.a + (size_t)(p + j) * g.partial_stride + (size_t)row * g.ld_a + lane * 4);
+                    }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    vv[rr].x += w[0][rr].x + w[1][rr].x; vv[rr].y += w[0][rr].y + w[1][rr].y;
+                    vv[rr].z += w[0][rr].z + w[1][rr].z; vv[rr].w += w[0][rr].w + w[1][rr].w;
+                }
             }
-            if (g.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            if (g.post && row < rows) {
-                const rac_f4 w = rac_ld4(g.post + (size_t)row * g.ld_post + lane * 4);
-                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-            }
-            *reinterpret_cast<rac_f4 *>(sX + r * LD + 256 * s + lane * 4) = v;
-            if (first_slice && row < rows) {
-                if (g.x_out)
-                    *reinterpret_cast<rac_f4 *>(g.x_out + (size_t)row * g.ld_xout + lane * 4) = v;
-                if (g.split_out) {   // f16 [hi | hi | lo | pad] image of v * split_scale (see rac_add_ln_fwd)
-                    rac_h4 hi, lo;
-                    rac_split_f16(v.x * g.split_scale, hi.x, lo.x);
-                    rac_split_f16(v.y * g.split_scale, hi.y, lo.y);
-                    rac_split_f16(v.z * g.split_scale, hi.z, lo.z);
-                    rac_split_f16(v.w * g.split_scale, hi.w, lo.w);
-                    _Float16 *dst = reinterpret_cast<_Float16 *>(g.split_out) + (size_t)row * (768 + g.split_pad);
-                    *reinterpret_cast<rac_h4 *>(dst + lane * 4) = hi;
-                    *reinterpret_cast<rac_h4 *>(dst + 256 + lane * 4) = hi;
-                    *reinterpret_cast<rac_h4 *>(dst + 512 + lane * 4) = lo;
-                    if (lane < g.split_pad)
-                        dst[768 + lane] = lane < 2 ? (_Float16)g.split_scale : (_Float16)0.f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = rbase + rr, row = row0 + r;
+                rac_f4 v = vv[rr];
+                if (row < rows) {
+                    v.x = v.x * g.a_scale + b0.x + rs[rr].x; v.y = v.y * g.a_scale + b0.y + rs[rr].y;
+                    v.z = v.z * g.a_scale + b0.z + rs[rr].z; v.w = v.w * g.a_scale + b0.w + rs[rr].w;
+                }
+                if (g.gamma) {
+                    const float mean = rg_wave_sum((v.x + v.y) + (v.z + v.w)) / 256.f;
+                    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+                    const float rstd = 1.f / sqrtf(rg_wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 256.f + g.eps);
+                    v.x = d0 * rstd * gm.x + bt.x; v.y = d1 * rstd * gm.y + bt.y;
+                    v.z = d2 * rstd * gm.z + bt.z; v.w = d3 * rstd * gm.w + bt.w;
+                }
+                if (g.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (g.post && row < rows) {
+                    const rac_f4 w = rac_ld4(g.post + (size_t)row * g.ld_post + lane * 4);
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+                *reinterpret_cast<rac_f4 *>(sX + r * LD + 256 * s + lane * 4) = v;
+                if (first_slice && row < rows) {
+                    if (g.x_out)
+                        *reinterpret_cast<rac_f4 *>(g.x_out + (size_t)row * g.ld_xout + lane * 4) = v;
+                    if (g.split_out) {   // f16 [hi | hi | lo | pad] image of v * split_scale (see rac_add_ln_fwd)
+                        rac_h4 hi, lo;
+                        rac_split_f16(v.x * g.split_scale, hi.x, lo.x);
+                        rac_split_f16(v.y * g.split_scale, hi.y, lo.y);
+                        rac_split_f16(v.z * g.split_scale, hi.z, lo.z);
+                        rac_split_f16(v.w * g.split_scale, hi.w, lo.w);
+                        _Float16 *dst = reinterpret_cast<_Float16 *>(g.split_out) + (size_t)row * (768 + g.split_pad);
+                        *reinterpret_cast<rac_h4 *>(dst + lane * 4) = hi;
+                        *reinterpret_cast<rac_h4 *>(dst + 256 + lane * 4) = hi;
+                        *reinterpret_cast<rac_h4 *>(dst + 512 + lane * 4) = lo;
+                        if (lane < g.split_pad)
+                            dst[768 + lane] = lane < 2 ? (_Float16)g.split_scale : (_Float16)0.f;
+                    }
                 }
             }
         }
     }
     __syncthreads();
 
-    // ---- GEMM: wave w owns columns n0 + 16w .. +15;  lane (li, lk): A row li, B column li, k = 16u + 4lk + i ----
-    const int li = lane & 15, lk = lane >> 4;
-    const int col = n0 + 16 * wave + li;
-    const int wrow = col < d.N ? col : d.N - 1;
+    // ---- GEMM ----
+    // weights of one 256-wide segment = 16 loads of 16 bytes per lane, all issued before the segment's MFMAs; the
+    // next segment's loads are issued before the current segment's MFMAs (one memory latency per launch, not per step)
     const float *ap = sX + li * LD + 4 * lk;
-    const float *bp = d.w + (size_t)wrow * K + 4 * lk;
-    rg_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int U = K / 16;
-#pragma unroll 8
-    for (int u = 0; u < U; ++u) {
-        const rac_f4 a4 = *reinterpret_cast<const rac_f4 *>(ap + 16 * u);
-        const rac_f4 b4 = rac_ld4(bp + 16 * u);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc1, 0, 0, 0);
+    rg_f4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        acc[m][0] = acc[m][1] = (rg_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sgm = 0; sgm < NSEG; ++sgm) {
+        if (sgm + 1 < NSEG) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                bnxt[u] = rac_ld4(bp + 256 * (sgm + 1) + 16 * ((u + rot) & 15));
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int ko = 256 * sgm + 16 * ((u + rot) & 15);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const rac_f4 a4 = *reinterpret_cast<const rac_f4 *>(ap + 16 * m * LD + ko);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bcur[u].x, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bcur[u].y, acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bcur[u].z, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bcur[u].w, acc[m][1], 0, 0, 0);
+            }
+        }
+        if (sgm + 1 < NSEG) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                bcur[u] = bnxt[u];
+        }
     }
     const float bv = d.b ? d.b[wrow] : 0.f;
     const bool relu = col >= d.relu_from;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = row0 + 4 * lk + r;
-        float v = (acc0[r] + acc1[r]) + bv;
-        if (relu)
-            v = fmaxf(v, 0.f);
-        if (row < rows && col < d.N)
-            d.out[(size_t)row * d.ld_out + col] = v;
-    }
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 16 * m + 4 * lk + r;
+            float v = (acc[m][0][r] + acc[m][1][r]) + bv;
+            if (relu)
+                v = fmaxf(v, 0.f);
+            if (row < rows && col < d.N)
+                d.out[(size_t)row * d.ld_out + col] = v;
+        }
 }
 
-__global__ __launch_bounds__(256) void rowgemm_kernel(const RowGemmArgs a)
+template <int NSEG, int MT>
+__global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs a)
 {
     extern __shared__ float smem[];
     const rac_rowgemm &d = a.d[blockIdx.z];
     if ((int)blockIdx.y * 64 >= d.N)
         return;   // (uniform per workgroup: batched GEMMs may have different widths)
-    if (d.num_seg == 1)
-        rowgemm_body<1>(d, a.rows, smem);
-    else if (d.num_seg == 2)
-        rowgemm_body<2>(d, a.rows, smem);
-    else
-        rowgemm_body<3>(d, a.rows, smem);
+    rowgemm_body<NSEG, MT>(d, a.rows, smem);
 }
 
 extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream)
@@ -170,12 +225,33 @@ extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void
             RAC_CHECK_ARG(!g.split_out || (g.split_pad >= 0 && g.split_pad <= 64 && g.split_pad % 4 == 0),
                           "rac_rowgemm_fwd: GEMM %d segment %d: split_pad=%d", i, s, g.split_pad);
         }
+        RAC_CHECK_ARG(d.num_seg == descs[0].num_seg, "rac_rowgemm_fwd: batched GEMMs must have the same number of segments");
         a.d[i] = d;
         max_n = d.N > max_n ? d.N : max_n;
         max_seg = d.num_seg > max_seg ? d.num_seg : max_seg;
     }
     a.rows = rows;
-    const size_t lds = (size_t)16 * (256 * max_seg + 4) * sizeof(float);
-    hipLaunchKernelGGL(rowgemm_kernel, dim3((rows + 15) / 16, (max_n + 63) / 64, num), dim3(256), lds, (hipStream_t)stream, a);
+    // 64-row tiles for single-segment GEMMs that are wide enough to fill the chip with them (N >= 512)
+    // (measured: slower for every N on the path -- 64-row tiles leave one latency-bound workgroup per CU; the 16-row
+    //  tiles' redundant weight reads are L2 hits.  Kept for experiments: RAC_ROWGEMM_TALL=1)
+    static const bool allow_tall = getenv("RAC_ROWGEMM_TALL") && atoi(getenv("RAC_ROWGEMM_TALL")) != 0;
+    const bool tall = allow_tall && max_seg == 1 && max_n >= 512;
+    const int R = tall ? 64 : 16;
+    const size_t lds = (size_t)R * (256 * max_seg + 4) * sizeof(float);
+    const dim3 grid((rows + R - 1) / R, (max_n + 63) / 64, num);
+    hipStream_t st = (hipStream_t)stream;
+    if (tall) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((rowgemm_kernel<1, 4>), grid, dim3(256), lds, st, a);
+    } else if (max_seg == 1)
+        hipLaunchKernelGGL((rowgemm_kernel<1, 1>), grid, dim3(256), lds, st, a);
+    else if (max_seg == 2)
+        hipLaunchKernelGGL((rowgemm_kernel<2, 1>), grid, dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL((rowgemm_kernel<3, 1>), grid, dim3(256), lds, st, a);
     return rac_launch_status("rac_rowgemm_fwd");
 }

@@ -358,9 +358,10 @@ class RadarBEVTemporalEncoder(nn.Module):
                 and C == 256 and self.hidden_dims % 32 == 0 and (H * W) % 256 == 0 and W % 4 == 0 and W <= 128
                 and self.temporal_fusion.kernel_size == (3, 3) and self.temporal_fusion.padding == (1, 1))
 
-    def forward_channel_last(self, bev_feats, packed):
-        """-> [B*T, H, W, C] (channel-last).  ``packed`` = pack_conv3x3_weight(temporal_fusion.weight)."""
-        x, hid = self.hidden_stream(bev_feats)
+    def forward_channel_last(self, bev_feats, packed, hidden=None):
+        """-> [B*T, H, W, C] (channel-last).  ``packed`` = pack_conv3x3_weight(temporal_fusion.weight) + (hidden_bound(),);
+        ``hidden``: hidden_stream(bev_feats) if the caller already ran it (on a side stream)."""
+        x, hid = hidden if hidden is not None else self.hidden_stream(bev_feats)
         # |ConvGRU state| <= 1 (convex combinations of tanh values, zero start), bilinear resizing keeps that, so
         # |hid| <= max_row ||W_up||_1 + max|b_up|: known from the weights, no need to scan the tensor
         return conv3x3_fused([x.contiguous(), hid.contiguous()], packed[0], packed[1], self.temporal_fusion.bias,
@@ -465,7 +466,7 @@ class BEVSampling(nn.Module):
         nn.init.uniform_(bias[:, 0:2], -0.5, 0.5)
         self.attention.init_weights()
 
-    def prepare_value(self, bev_feats, conv_pack=None):
+    def prepare_value(self, bev_feats, conv_pack=None, hidden=None):
         """Query-independent half of inner_forward (:484-485, :532-537 + value_proj): temporal
         encoder (radar only), + learned positional encoding, value projection.  ``conv_pack``: the packed
         temporal_fusion weights (fused convolution kernel, channel-last output) or None (MIOpen)."""
@@ -474,7 +475,7 @@ class BEVSampling(nn.Module):
         if self.temp_radar:
             if conv_pack is not None and conv_pack[0] is not None and self.temporal_encoder.fused_conv_supported(bev_feats):
                 B, T = bev_feats.shape[:2]
-                nhwc = self.temporal_encoder.forward_channel_last(bev_feats, conv_pack)
+                nhwc = self.temporal_encoder.forward_channel_last(bev_feats, conv_pack, hidden() if callable(hidden) else hidden)
                 return self.attention.project_value(nhwc.view(B, T, H, W, -1), pos, channel_last=True), (H, W)
             bev_feats = self.temporal_encoder(bev_feats)
         return self.attention.project_value(bev_feats, pos), (H, W)
@@ -757,15 +758,17 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         widths = [m.weight.shape[0] for m in mods]
         return w, b, widths
 
-    def prepare(self, lss_bev_feats, radar_bev_feats):
-        """Layer-invariant tensors (computed once per forward)."""
+    def prepare(self, lss_bev_feats, radar_bev_feats, radar_hidden=None):
+        """Layer-invariant tensors (computed once per forward).  ``radar_hidden``: a callable returning
+        temporal_encoder.hidden_stream(radar_bev_feats) computed elsewhere (it is called right before the result is
+        needed, i.e. after the LSS value stream has been enqueued)."""
         te = self.sampling_radar_bev.temporal_encoder
         up = te.upsample[1]
         conv_pack = self._cached("conv_pack", [te.temporal_fusion.weight, up.weight] + ([up.bias] if up.bias is not None else []),
                                  lambda: pack_conv3x3_weight(te.temporal_fusion.weight) + (te.hidden_bound(),)) \
             if radar_bev_feats.is_cuda and self.fused and te.fused_conv else None
-        radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack)
         lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
+        radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack, radar_hidden)
         rb, lb, mix = self.sampling_radar_bev, self.sampling_lss_bev, self.mixing
         wide_mods = [self.sampling.sampling_offset, self.sampling.ray_points_offset, self.sampling.scale_weights]
         for x in (rb, lb):
@@ -847,11 +850,13 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         ro, lo = rb.attention.output_proj, lb.attention.output_proj
         rowgemm_launch([row_gemm([row_seg(bev[0])], ro.weight, ro.bias, proj[0]),
                         row_gemm([row_seg(bev[1])], lo.weight, lo.bias, proj[1])], n)
-        # fusion Linear over [norm2(mixing) | norm_radar(radar) | norm_lss(lss)], each third normalised in the prologue
-        S = partials.shape[0]
+        # fusion Linear over [norm2(mixing) | norm_radar(radar) | norm_lss(lss)]: the split-K sum + norm2 is its own row-wise
+        # launch (16 partial rows per row are latency-bound inside a GEMM prologue: 32 us against 5 + 15), the two BEV
+        # thirds are normalised in the GEMM's prologue
+        x2 = add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0],
+                    a_scale=p_scale)
         f_raw = new(n, E)
-        rowgemm_launch([row_gemm([row_seg(partials, num_partials=S, a_scale=p_scale, bias0=self.mixing.out_proj.bias,
-                                          residual=x1, norm=self.norm2),
+        rowgemm_launch([row_gemm([row_seg(x2),
                                   row_seg(proj[0], residual=x1, norm=self.norm_radar_bev),
                                   row_seg(proj[1], residual=x1, norm=self.norm_lss_bev)],
                                  self.fusion.weight, self.fusion.bias, f_raw)], n)
@@ -1058,6 +1063,9 @@ class RaCFormerTransformerDecoder(nn.Module):
         # True: ``mlvl_feats`` arrive already in the sampling layout [B*T*G, N, H, W, C] (a producer that writes the
         # grouped channel-last pyramid directly skips the 1.47 GB regroup)
         self.pregrouped = False
+        # ConvGRU chain on a second stream beside the regroup: measured 143.2 vs 145.6 samples/s (slower) -- the regroup
+        # already saturates HBM and the chain's convolutions then wait on it; stays off.
+        self.overlap_prepare = False
 
     @torch.no_grad()
     def init_weights(self):
@@ -1093,6 +1101,22 @@ class RaCFormerTransformerDecoder(nn.Module):
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
                 stages_per_layer=None):
         self.stage_metas(img_metas, query_bbox.shape[0], query_bbox.device)
+        # The ConvGRU half of the radar temporal encoder is ~25 small launch-bound kernels (downsample, 4 GRU steps, resize,
+        # 3x3 conv): it runs on a second HIP stream beside the HBM-bound pyramid regroup and the LSS value projection.
+        layer = self.decoder_layer
+        te = layer.sampling_radar_bev.temporal_encoder
+        radar_hidden = None
+        if self.overlap_prepare and query_bbox.is_cuda and layer.fused and te.fused_conv_supported(radar_bev_feats):
+            main, side = torch.cuda.current_stream(), layer._side_stream(query_bbox.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                hidden = te.hidden_stream(radar_bev_feats)
+            for t in hidden:
+                t.record_stream(main)
+
+            def radar_hidden():
+                main.wait_stream(side)
+                return hidden
         if self.pregrouped:
             # producer-side layout: the FPN already wrote [B*T*G, N, H, W, C]
             for f in mlvl_feats:
@@ -1102,7 +1126,7 @@ class RaCFormerTransformerDecoder(nn.Module):
             grouped = regroup_pyramid(mlvl_feats, self.num_cams, 4, self.feature_dtype)
             for lvl, g in enumerate(grouped):
                 mlvl_feats[lvl] = g  # the reference mutates the caller's list too (:124)
-        prepared = self.decoder_layer.prepare(lss_bev_feats, radar_bev_feats)
+        prepared = self.decoder_layer.prepare(lss_bev_feats, radar_bev_feats, radar_hidden)
         cls_scores, bbox_preds = [], []
         for i in range(self.num_layers):
             st = {} if stages_per_layer is not None else None

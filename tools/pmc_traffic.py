@@ -20,7 +20,7 @@ def main():
     fetch, write = load(dfetch, "FETCH_SIZE"), load(dwrite, "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(s in k for s in ("sampling4d", "bev_sampling", "msmv_fwd", "msda_fwd", "regroup", "sasa", "mixing")):
+        if not any(s in k for s in ("sampling4d", "bev_sampling", "msmv_fwd", "msda_fwd", "regroup", "sasa", "mixing", "conv3x3", "conv_pack", "rowgemm", "absmax")):
             continue
         f = fetch.get(k, [])
         w = write.get(k, [])

@@ -32,6 +32,7 @@
  *                        models/racformer_transformer.py:589-603
  *   rac_sasa_fwd      <- ScaleAdaptiveSelfAttention.inner_forward's mask + attention product
  *                        models/racformer_transformer.py:296-335
+ *   rac_gemm_f16x3_fwd <- AdaptiveMixing.parameter_generator (nn.Linear 256 -> 65536), models/racformer_transformer.py:565,589
  *   rac_rowgemm_fwd   <- nn.Linear + its preceding add / LayerNorm / ReLU groups, models/racformer_transformer.py:170-177, 243-269
  *   rac_gru_gate_fwd / rac_upsample2x_fwd <- ConvGRUCell.forward's element-wise tail, nn.Upsample
  *                        models/racformer_transformer.py:705-720, :633-636
@@ -252,13 +253,17 @@ int rac_upsample2x_fwd(const float *src, float *dst, int64_t planes, int h, int 
  * the finished segment; split_out (optional) its f16 [hi | hi | lo | pad] image (layout of rac_add_ln_fwd's split_out).
  * Up to RAC_ROWGEMM_MAX_BATCH independent GEMMs over the same `rows` share the launch (descs: HOST array). */
 #define RAC_ROWGEMM_MAX_BATCH 3
+enum {
+    RAC_SPLIT_KCAT = 0,    /* split_out rows [hi 256 | hi 256 | lo 256 | pad]: A operand of a K-concatenated library GEMM */
+    RAC_SPLIT_CHUNKED = 1  /* split_out rows [8 chunks][hi 32 | lo 32] (1 KB): A image of rac_gemm_f16x3_fwd */
+};
 typedef struct {
     const float *a;
     int64_t partial_stride;
     const float *bias0, *residual, *gamma, *beta, *post;
     float *x_out;
     void *split_out;
-    int ld_a, num_partials, ld_res, ld_post, ld_xout, relu, split_pad;
+    int ld_a, num_partials, ld_res, ld_post, ld_xout, relu, split_pad, split_layout;
     float a_scale, eps, split_scale;
 } rac_rowseg;
 typedef struct {
@@ -268,6 +273,15 @@ typedef struct {
     int num_seg, N, ld_out, relu_from;
 } rac_rowgemm;
 int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream);
+
+/* Split-precision GEMM on the f16 matrix cores (3 products, fp32 accumulate, fp32-GEMM accuracy; hand-written, same inner
+ * loop as rac_conv3x3_fwd):  out[M][N] = alpha * (A @ W^T) + bias.  Replaces the nn.Linear `parameter_generator` of
+ * AdaptiveMixing (models/racformer_transformer.py:565,589).
+ *   a_img : device f16 [M][K/32][hi 32 | lo 32] of A * 2^a  (rac_rowgemm_fwd writes it: split_layout = RAC_SPLIT_CHUNKED)
+ *   w_img : device f16 [K/32][N][hi 32 | lo 32] of W * 2^s  (packed once by the host);  alpha = 2^-(a+s)
+ *   out   : device f32, row stride ld_out;  N % 256 == 0, K % 32 == 0 */
+int rac_gemm_f16x3_fwd(const void *a_img, const void *w_img, const float *bias, float alpha, float *out, int ld_out, int M,
+                       int N, int K, void *stream);
 
 /* Backward of the two gather operators (SURVEY.md section 8 "next" row f4; fp32 features only).
  * rac_msmv_bwd  <- _ms_deform_attn_cuda_{c45,c2345,c23456}_backward, models/csrc/msmv_sampling/msmv_sampling.cpp:302-497

@@ -35,6 +35,7 @@ SIGNATURES = {
     "rac_refine_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_f, _vp]),
     "rac_mixing_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _f] + [_i] * 6 + [_f, _i, _vp]),
     "rac_sasa_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
+    "rac_gemm_f16x3_fwd": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "rac_rowgemm_fwd": (_i, [_vp, _i, _i, _vp]),
     "rac_gru_gate_fwd": (_i, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
     "rac_upsample2x_fwd": (_i, [_vp, _vp, ctypes.c_int64, _i, _i, _vp]),
@@ -49,7 +50,7 @@ class RowSeg(ctypes.Structure):
     """rac_rowseg (include/racformer_hip.h)"""
     _fields_ = [("a", _vp), ("partial_stride", ctypes.c_int64), ("bias0", _vp), ("residual", _vp), ("gamma", _vp),
                 ("beta", _vp), ("post", _vp), ("x_out", _vp), ("split_out", _vp), ("ld_a", _i), ("num_partials", _i),
-                ("ld_res", _i), ("ld_post", _i), ("ld_xout", _i), ("relu", _i), ("split_pad", _i), ("a_scale", _f),
+                ("ld_res", _i), ("ld_post", _i), ("ld_xout", _i), ("relu", _i), ("split_pad", _i), ("split_layout", _i), ("a_scale", _f),
                 ("eps", _f), ("split_scale", _f)]
 
 

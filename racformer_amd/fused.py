@@ -434,11 +434,12 @@ def _rows2d(t, what):
 
 
 def row_seg(a, num_partials=1, a_scale=1.0, bias0=None, residual=None, norm=None, relu=False, post=None, x_out=None,
-            split_out=None):
+            split_out=None, split_chunked=False):
     """One 256-wide segment of a rowgemm's A operand (see rac_rowgemm_fwd):
     [relu](LN_norm(a_scale * sum_p a[p] + bias0 + residual)) [+ post]; ``a`` is [rows,256] (any row stride) or, with
     num_partials = S > 1, a contiguous [S, rows, 256].  ``x_out`` / ``split_out``: destinations for the finished rows
-    (fp32 [rows,256] / f16 [rows, 768 + SPLIT_BIAS_PAD])."""
+    (fp32 [rows,256] / f16 [rows, 768 + SPLIT_BIAS_PAD], or f16 [rows, 512] = [8 chunks][hi 32 | lo 32] with
+    ``split_chunked``: the A image of ``gemm_f16x3``)."""
     g = _lib.RowSeg()
     keep = []
     if num_partials > 1:
@@ -468,9 +469,11 @@ def row_seg(a, num_partials=1, a_scale=1.0, bias0=None, residual=None, norm=None
         t, g.x_out, g.ld_xout = _rows2d(x_out, "x_out")
         keep.append(t)
     if split_out is not None:
-        if split_out.dtype != torch.float16 or not split_out.is_contiguous() or split_out.shape[-1] != 768 + SPLIT_BIAS_PAD:
-            raise RuntimeError("row_seg: split_out must be a contiguous f16 [rows, 768 + SPLIT_BIAS_PAD] tensor")
-        g.split_out, g.split_scale, g.split_pad = ctypes.c_void_p(split_out.data_ptr()), SPLIT_ACT_SCALE, SPLIT_BIAS_PAD
+        width = 512 if split_chunked else 768 + SPLIT_BIAS_PAD
+        if split_out.dtype != torch.float16 or not split_out.is_contiguous() or split_out.shape[-1] != width:
+            raise RuntimeError(f"row_seg: split_out must be a contiguous f16 [rows, {width}] tensor")
+        g.split_out, g.split_scale = ctypes.c_void_p(split_out.data_ptr()), SPLIT_ACT_SCALE
+        g.split_pad, g.split_layout = (0, 1) if split_chunked else (SPLIT_BIAS_PAD, 0)
         keep.append(split_out)
     g._keep = keep
     return g
@@ -500,3 +503,35 @@ def rowgemm_launch(descs, rows):
     arr = (_lib.RowGemm * len(descs))(*descs)
     rc = _lib.lib().rac_rowgemm_fwd(arr, len(descs), int(rows), _lib.stream_ptr())
     _lib.check(rc, "rac_rowgemm_fwd")
+
+
+# ------------------------------------------------------------------------------------------- split-precision GEMM
+def pack_gemm_weight_f16x3(weight):
+    """nn.Linear weight [N, K] fp32 -> (f16 [K/32, N, 2, 32] = hi / lo of weight * 2^s per 32-wide k chunk, alpha) for
+    rac_gemm_f16x3_fwd; alpha = 2^-s / SPLIT_ACT_SCALE undoes both power-of-two scalings.  (None, None) if f16 cannot
+    hold the weights or the shape does not fit the kernel (N % 256, K % 32)."""
+    import math
+    w = weight.detach().float()
+    N, K = w.shape
+    amax = float(w.abs().max())
+    if N % 256 != 0 or K % 32 != 0 or not (amax > 0.0) or amax != amax or amax == float("inf"):
+        return None, None
+    s = 13 - math.frexp(amax)[1] + 1
+    ws = (w * (2.0 ** s)).view(N, K // 32, 32).permute(1, 0, 2)          # [chunk, n, 32]
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    return torch.stack([hi, lo], dim=2).contiguous(), 2.0 ** (-s) / SPLIT_ACT_SCALE
+
+
+def gemm_f16x3(a_img, w_img, bias, alpha):
+    """a_img f16 [M, K/32 * 64] (row_seg(split_chunked=True)), w_img f16 [K/32, N, 2, 32] -> fp32 [M, N] = alpha * A @ W^T + bias."""
+    _lib.require_gpu(a_img, w_img, what="gemm_f16x3")
+    M = a_img.shape[0]
+    chunks, N = w_img.shape[0], w_img.shape[1]
+    if a_img.dtype != torch.float16 or w_img.dtype != torch.float16 or a_img.shape[1] != chunks * 64:
+        raise RuntimeError("gemm_f16x3: operand images do not match")
+    out = torch.empty(M, N, device=a_img.device, dtype=torch.float32)
+    rc = _lib.lib().rac_gemm_f16x3_fwd(_lib.ptr(a_img), _lib.ptr(w_img), _lib.ptr(bias) if bias is not None else None,
+                                       float(alpha), _lib.ptr(out), N, M, N, chunks * 32, _lib.stream_ptr())
+    _lib.check(rc, "rac_gemm_f16x3_fwd")
+    return out

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, row_gemm, row_seg, rowgemm_launch, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, gemm_f16x3, pack_gemm_weight_f16x3, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, row_gemm, row_seg, rowgemm_launch, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
                     pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
 from .msda import msda_forward
 from .msmv import msmv_forward
@@ -585,7 +585,11 @@ class AdaptiveMixing(nn.Module):
         ow, out_alpha = split_weight_f16(w.detach().view(N, S, self.SPLIT_SLICE).permute(1, 0, 2).reshape(S * N, self.SPLIT_SLICE))
         if ow is None:
             return {}
-        return dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow.view(S, N, 3 * self.SPLIT_SLICE), out_alpha=out_alpha)
+        packs = dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow.view(S, N, 3 * self.SPLIT_SLICE), out_alpha=out_alpha)
+        gen_img, gen_img_alpha = pack_gemm_weight_f16x3(gen.weight)       # image of the hand-written GEMM (rac_gemm_f16x3_fwd)
+        if gen_img is not None:
+            packs.update(gen_img=gen_img, gen_img_alpha=gen_img_alpha)
+        return packs
 
     def out_proj_partials(self, x, query, out_proj_split, params=None, packs=None, query_split=None):
         """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
@@ -603,7 +607,11 @@ class AdaptiveMixing(nn.Module):
             ev = timer.record("mixing_generator_gemm") if timer is not None else None
             if ev:
                 ev[0].record()
-            if split:
+            if split and query_split.shape[-1] == 2 * self.query_dim:
+                # chunked [hi 32 | lo 32] image: the hand-written split-precision GEMM (bias and alpha in its epilogue)
+                params = gemm_f16x3(query_split, packs["gen_img"], self.parameter_generator.bias,
+                                    packs["gen_img_alpha"]).view(B, Q, -1)
+            elif split:
                 # bias rides in the K-concatenated operands; alpha (a power of two) is applied by the mixing kernel
                 params = torch.mm(query_split, packs["gen_w"].t(), out_dtype=torch.float32).view(B, Q, -1)
                 params_scaled = True
@@ -713,6 +721,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # producer's normalisation runs as the prologue of its consumer GEMM): 21 launches per layer instead of ~50.
         # False: library GEMMs + rac_add_ln_fwd launches (forward_fused_chain).
         self.rowgemm = True
+        # parameter generator on the hand-written split-precision GEMM (rac_gemm_f16x3_fwd) instead of hipBLASLt over the
+        # K-concatenated images.  Measured 158 us against 130 us (8 K-steps per 256x256 tile: the two-stage register pipeline
+        # of the convolution kernel does not hide the first-load and store latencies of so short a K loop), so it is off.
+        self.own_gemm = False
         self._pack_cache = {}
 
     def _cached(self, key, params, fn):
@@ -826,9 +838,11 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         rowgemm_launch([row_gemm([row_seg(o)], p.out_proj.weight, p.out_proj.bias, attn)], n)
         # x1 = norm1(x + attn) (+ its f16 image for the generator GEMM);  the eleven Linears of the three sampling modules
         x1 = new(B, Q, E)
-        x1_split = torch.empty(n, 3 * E + SPLIT_BIAS_PAD, device=dev, dtype=torch.float16) if packs else None
+        own_gemm = bool(packs) and self.own_gemm and "gen_img" in packs
+        x1_split = torch.empty(n, 2 * E if own_gemm else 3 * E + SPLIT_BIAS_PAD, device=dev, dtype=torch.float16) if packs else None
         wide = new(B, Q, prepared["wide_w"].shape[0])
-        rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split)],
+        rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split,
+                                          split_chunked=own_gemm)],
                                  prepared["wide_w"], prepared["wide_b"], wide)], n)
         lin = wide.split(prepared["wide_widths"], dim=-1)
         rb, lb = self.sampling_radar_bev, self.sampling_lss_bev

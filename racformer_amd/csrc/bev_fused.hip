@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
     float *sbase = sq + BEV_GI * T;            // [GI][P][2]  T-invariant base points (B==1)
     float *sdoff = sbase + BEV_GI * P * 2;     // [GI][D]
     float *spart = sdoff + BEV_GI * BEV_MAX_DEPTH;  // [GI][TS][64] partial sums
+    float *stab = spart + BEV_GI * BEV_TS * 64;     // [GI][T][P][8]: 4 tap pixel indices (int, -1 = outside) + 4 tap weights
 
     // phase A: T-invariant pieces.  threads [0, GI*P): base points; [128,128+GI*D): depth offsets;
     // [192,192+GI): softmaxes of the point weights and of the frame weights.
@@ -199,6 +200,29 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
                 s2 += expf(lg[pj] - wmax);
             sattn[(kk * T + t) * P + p] = expf(lg[p] - wmax) / s2;
         }
+        {
+            // Tap table of this keypoint: bilinear footprint (Deformable-DETR semantics, align_corners=False, zero padding),
+            // the point's attention weight and the frame weight folded into the four tap weights.  Computed once here
+            // (one thread per keypoint) instead of by each of the 16 lanes that later gather the point.
+            const float wgt = sattn[(kk * Tw + (a.B > 1 ? t : 0)) * P + p] * sq[kk * T + t];
+            const int Hh = a.H, Ww = a.W;
+            const float h_im = sloc[i * 2 + 1] * (float)Hh - 0.5f, w_im = sloc[i * 2] * (float)Ww - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)Hh && w_im < (float)Ww;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= Hh - 1;
+            const bool l_ok = w_low >= 0, r_ok = w_high <= Ww - 1;
+            int *ti = reinterpret_cast<int *>(stab + i * 8);
+            ti[0] = t_ok && l_ok ? h_low * Ww + w_low : -1;
+            ti[1] = t_ok && r_ok ? h_low * Ww + w_high : -1;
+            ti[2] = b_ok && l_ok ? h_high * Ww + w_low : -1;
+            ti[3] = b_ok && r_ok ? h_high * Ww + w_high : -1;
+            stab[i * 8 + 4] = hh * hw * wgt;
+            stab[i * 8 + 5] = hh * lw * wgt;
+            stab[i * 8 + 6] = lh * hw * wgt;
+            stab[i * 8 + 7] = lh * lw * wgt;
+        }
         if (a.loc_out) {
             float *lo = a.loc_out + (((((size_t)b * a.Q + q) * a.heads + h) * T + t) * P + p) * 2;
             lo[0] = sloc[i * 2];
@@ -218,7 +242,6 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
         // chip works on (nearly) one 16.8 MB frame at a time, which the L2s / Infinity Cache hold better than four.
         const int npp = (P - ts + BEV_TS - 1) / BEV_TS;   // this subset's points per frame
         const int total = T * npp;
-        const float *qw = sq + k * T;
         for (int j0 = 0; j0 < total; j0 += 4) {
             rac_f4 v[4][4];
             float tw[4][4];
@@ -229,24 +252,17 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
                 const int jj = act ? j : total - 1;
                 const int t = jj / npp, p = ts + BEV_TS * (jj - t * npp);
                 const FT *base = (const FT *)a.value + ((size_t)(b * T + t) * keys * a.heads + h) * 64 + c4 * 4;
-                const float *lp = sloc + (k * TP + t * P + p) * 2;
-                const float x = lp[0], y = lp[1];
-                const float wgt = act ? sattn[(k * Tw + (a.B > 1 ? t : 0)) * P + p] * qw[t] : 0.f;
-                const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
-                const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                const float hf = floorf(h_im), wf = floorf(w_im);
-                const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
-                const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-                v[u][0] = bev_tap(base, (long)h_low * W + w_low, stride, t_ok && l_ok);
-                v[u][1] = bev_tap(base, (long)h_low * W + w_high, stride, t_ok && r_ok);
-                v[u][2] = bev_tap(base, (long)h_high * W + w_low, stride, b_ok && l_ok);
-                v[u][3] = bev_tap(base, (long)h_high * W + w_high, stride, b_ok && r_ok);
-                tw[u][0] = hh * hw * wgt;
-                tw[u][1] = hh * lw * wgt;
-                tw[u][2] = lh * hw * wgt;
-                tw[u][3] = lh * lw * wgt;
+                const float *e = stab + (k * TP + t * P + p) * 8;          // same address for the 16 lanes of the group
+                const rac_f4 ei = *reinterpret_cast<const rac_f4 *>(e), ew = *reinterpret_cast<const rac_f4 *>(e + 4);
+                const int o0 = __float_as_int(ei.x), o1 = __float_as_int(ei.y), o2 = __float_as_int(ei.z), o3 = __float_as_int(ei.w);
+                v[u][0] = bev_tap(base, (long)o0, stride, act && o0 >= 0);
+                v[u][1] = bev_tap(base, (long)o1, stride, act && o1 >= 0);
+                v[u][2] = bev_tap(base, (long)o2, stride, act && o2 >= 0);
+                v[u][3] = bev_tap(base, (long)o3, stride, act && o3 >= 0);
+                tw[u][0] = act ? ew.x : 0.f;
+                tw[u][1] = act ? ew.y : 0.f;
+                tw[u][2] = act ? ew.z : 0.f;
+                tw[u][3] = act ? ew.w : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -285,7 +301,7 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
     RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_bev_sampling_fwd: dtype %d", dtype);
     const int P = NP * D;
     const size_t lds = ((size_t)BEV_GI * T * P * 2 + (size_t)BEV_GI * (B > 1 ? T : 1) * P + (size_t)BEV_GI * T + (size_t)BEV_GI * P * 2 +
-                        (size_t)BEV_GI * BEV_MAX_DEPTH + (size_t)BEV_GI * BEV_TS * 64) * sizeof(float);
+                        (size_t)BEV_GI * BEV_MAX_DEPTH + (size_t)BEV_GI * BEV_TS * 64 + (size_t)BEV_GI * T * P * 8) * sizeof(float);
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_bev_sampling_fwd: T*P=%d too large for the LDS staging", T * P);
     if (B == 0 || Q == 0)
         return 0;

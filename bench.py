@@ -47,6 +47,7 @@ def build_head(cfg, device, feature_dtype=torch.float32):
         head.init_query_bbox.weight.copy_(syn.make_queries(cfg, 0)[0][0])
     head.transformer.decoder.feature_dtype = feature_dtype
     head.transformer.decoder.overlap_prepare = os.environ.get("RAC_OVERLAP_PREPARE", "0") != "0"   # experiment switch
+    head.transformer.decoder.decoder_layer.own_gemm = os.environ.get("RAC_OWN_GEMM", "0") != "0"   # experiment switch
     return head.eval().to(device)
 
 

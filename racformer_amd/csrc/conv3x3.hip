@@ -16,8 +16,8 @@
 //   output       out [N][H][W][256] f32 (channel-last: what value_proj's GEMM reads as its A operand)
 // Workgroup = 512 threads = 8 waves (2 along pixels x 4 along channels), tile = 256 consecutive pixels of one
 // image x 256 output channels, K loop over 9 taps x Cin/32 chunks.  Per K-step 64 KB (A 32 KB + B 32 KB) go
-// global -> registers -> LDS (two LDS stages = 128 KB, the loads of step k+1 are issued before the MFMAs of
-// step k and written after them; one barrier per step), fragments are 16-byte LDS reads made conflict-free by an
+// global -> registers -> LDS (two LDS stages = 128 KB; tile k+1 is written to LDS at the start of step k and the
+// registers re-used for the loads of tile k+2, which land under step k's MFMAs; one barrier per step), fragments are 16-byte LDS reads made conflict-free by an
 // XOR swizzle of the 16-byte slots (slot ^ ((row >> 1) & 7)), 96 MFMAs per wave and step.
 #include "rac_common.h"
 #include <string.h>
@@ -168,12 +168,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
     }
     const int arow0 = 128 * wm + li;
 
+    // Pipeline: the registers always hold the tile after the one being multiplied.  At the top of step ks they (tile ks+1,
+    // loaded during step ks-1) are written to the other LDS stage -- free since the barrier that ended step ks-1 -- and
+    // immediately re-used for the loads of tile ks+2, which then have the whole MFMA phase to land; the LDS writes sit at
+    // the start of a step, not between the last MFMA and the barrier.
     CV_GLOAD(0);
     CV_LSTORE(0);
+    CV_GLOAD(KS > 1 ? 1 : 0);
     __syncthreads();
     for (int ks = 0; ks < KS; ++ks) {
-        // (the last step re-fetches its own tile: unconditional loads keep the staging registers out of scratch)
-        const int kn = ks + 1 < KS ? ks + 1 : ks;
+        // (past the end the last tile is re-fetched / re-written into the unused stage: unconditional code keeps the
+        //  staging registers out of scratch)
+        CV_LSTORE((ks + 1) & 1);
+        const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
         CV_GLOAD(kn);
         const cv_h8 *S = reinterpret_cast<const cv_h8 *>(lds4 + (ks & 1) * CV_STAGE_U4);
         cv_h8 bh[4], bl[4];
@@ -197,7 +204,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
             for (int nn = 0; nn < 4; ++nn)
                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nn], acc[m][nn], 0, 0, 0);
         }
-        CV_LSTORE((ks + 1) & 1);
         __syncthreads();
     }
 
@@ -284,9 +290,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_kernel(const GemmArgs a)
 
     GM_GLOAD(0);
     CV_LSTORE(0);
+    GM_GLOAD(KS > 1 ? 1 : 0);
     __syncthreads();
     for (int ks = 0; ks < KS; ++ks) {
-        const int kn = ks + 1 < KS ? ks + 1 : ks;
+        CV_LSTORE((ks + 1) & 1);
+        const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
         GM_GLOAD(kn);
         const cv_h8 *S = reinterpret_cast<const cv_h8 *>(lds4 + (ks & 1) * CV_STAGE_U4);
         cv_h8 bh[4], bl[4];
@@ -310,7 +318,6 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_kernel(const GemmArgs a)
             for (int nn = 0; nn < 4; ++nn)
                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nn], acc[m][nn], 0, 0, 0);
         }
-        CV_LSTORE((ks + 1) & 1);
         __syncthreads();
     }
 #pragma unroll

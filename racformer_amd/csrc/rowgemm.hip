@@ -238,23 +238,24 @@ extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void
         max_seg = d.num_seg > max_seg ? d.num_seg : max_seg;
     }
     a.rows = rows;
-    // 64-row tiles for single-segment GEMMs that are wide enough to fill the chip with them (N >= 512)
-    // (measured: slower for every N on the path -- 64-row tiles leave one latency-bound workgroup per CU; the 16-row
-    //  tiles' redundant weight reads are L2 hits.  Kept for experiments: RAC_ROWGEMM_TALL=1)
-    static const bool allow_tall = getenv("RAC_ROWGEMM_TALL") && atoi(getenv("RAC_ROWGEMM_TALL")) != 0;
-    const bool tall = allow_tall && max_seg == 1 && max_n >= 512;
-    const int R = tall ? 64 : 16;
+    // Row-tile height for single-segment GEMMs: RAC_ROWGEMM_MT = 1 (16 rows), 2 (32) or 4 (64) for N >= 512 -- taller tiles
+    // re-read the weights fewer times but leave fewer, longer workgroups.  Default 1 (measured: see DESIGN.md section 3.8).
+    static const int mt_env = getenv("RAC_ROWGEMM_MT") ? atoi(getenv("RAC_ROWGEMM_MT")) : 1;
+    const int MT = (max_seg == 1 && max_n >= 512 && (mt_env == 2 || mt_env == 4)) ? mt_env : 1;
+    const int R = 16 * MT;
     const size_t lds = (size_t)R * (256 * max_seg + 4) * sizeof(float);
     const dim3 grid((rows + R - 1) / R, (max_n + 63) / 64, num);
     hipStream_t st = (hipStream_t)stream;
-    if (tall) {
+    if (MT == 4) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
         hipLaunchKernelGGL((rowgemm_kernel<1, 4>), grid, dim3(256), lds, st, a);
-    } else if (max_seg == 1)
+    } else if (MT == 2)
+        hipLaunchKernelGGL((rowgemm_kernel<1, 2>), grid, dim3(256), lds, st, a);
+    else if (max_seg == 1)
         hipLaunchKernelGGL((rowgemm_kernel<1, 1>), grid, dim3(256), lds, st, a);
     else if (max_seg == 2)
         hipLaunchKernelGGL((rowgemm_kernel<2, 1>), grid, dim3(256), lds, st, a);

@@ -224,15 +224,16 @@ int rac_mixing_fwd(const float *x, const float *params, float param_scale, float
  *                     xs = f16 [N][H+2][W+2][c_total/32][2][32] (per pixel and 32-channel chunk: hi, then lo, of
  *                     v * 2^e; e from *amax).  Only interior pixels are written: the caller zeroes xs once (border =
  *                     the convolution's zero padding).  W % 4 == 0, W <= 128, channel counts multiples of 32.
- *   rac_conv3x3_fwd   out [N,H,W,256] f32 (channel-last) = conv3x3(xs) * w_alpha / 2^e + bias, with
+ *   rac_conv3x3_fwd   out [N,H,W,256] f32 (channel-last) = conv3x3(xs) * w_alpha / 2^e + bias[c] (or + pixel_bias[h*W+w][c]
+ *                     if pixel_bias != NULL: a per-pixel additive map shared by the N images), with
  *                     ws = f16 [9 taps (ky*3+kx)][Cin/32][256][2][32] holding hi / lo of weight[co][ci][ky][kx] / w_alpha
  *                     (w_alpha a power of two chosen by the packer).  H*W must be a multiple of 256. */
 int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float floor_value, float *amax_out,
                    void *stream);
 int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, int N, int C, int H, int W, int c_total,
                       int c_offset, void *stream);
-int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
-                    int N, int H, int W, int Cin, int Cout, void *stream);
+int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
+                    float w_alpha, float *out, int N, int H, int W, int Cin, int Cout, void *stream);
 
 /* Element-wise pieces of RadarBEVTemporalEncoder (models/racformer_transformer.py:618-720).
  *   rac_gru_gate_fwd   ConvGRUCell update after the gates convolution (:705-720): gates [B,3C,H,W] (z | r | cand),

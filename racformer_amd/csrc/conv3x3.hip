@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict_
 struct ConvArgs {
     const uint4 *xs;
     const uint4 *ws;
-    const float *bias;
+    const float *bias;        // [256] per output channel, or
+    const float *pixel_bias;  // [H*W][256] per pixel of an image and output channel (then bias is unused)
     const float *amax;
     float *out;
     int N, H, W, chunks;
@@ -217,19 +218,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
         __syncthreads();
     }
 
-    // epilogue: undo the two power-of-two scalings, add the bias, channel-last store
+    // epilogue: undo the two power-of-two scalings, add the bias (per channel, or per pixel and channel), channel-last store
     const float unscale = a.w_alpha / cv_act_scale(*a.amax);
     float *obase = a.out + ((size_t)n * H * W + (size_t)tile * CV_TM) * CV_COUT;
+    const float *pbase = a.pixel_bias ? a.pixel_bias + (size_t)tile * CV_TM * CV_COUT : nullptr;
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
         const int col = 64 * wn + 16 * nn + li;
-        const float bv = a.bias ? a.bias[col] : 0.f;
+        const float bv = (!pbase && a.bias) ? a.bias[col] : 0.f;
 #pragma unroll
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int p = 128 * wm + 16 * m + 4 * lk + r;
-                obase[(size_t)p * CV_COUT + col] = acc[m][nn][r] * unscale + bv;
+                const float pb = pbase ? pbase[(size_t)p * CV_COUT + col] : bv;
+                obase[(size_t)p * CV_COUT + col] = acc[m][nn][r] * unscale + pb;
             }
     }
 }
@@ -386,8 +389,8 @@ extern "C" int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, 
     return rac_launch_status("rac_conv_pack_fwd");
 }
 
-extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha,
-                               float *out, int N, int H, int W, int Cin, int Cout, void *stream)
+extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
+                               float w_alpha, float *out, int N, int H, int W, int Cin, int Cout, void *stream)
 {
     RAC_CHECK_ARG(Cout == CV_COUT, "rac_conv3x3_fwd: built for %d output channels (got %d)", CV_COUT, Cout);
     RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "rac_conv3x3_fwd: Cin=%d (multiple of 32)", Cin);
@@ -398,7 +401,7 @@ extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias
     ConvArgs a;
     a.xs = reinterpret_cast<const uint4 *>(xs);
     a.ws = reinterpret_cast<const uint4 *>(ws);
-    a.bias = bias; a.amax = amax; a.out = out;
+    a.bias = bias; a.pixel_bias = pixel_bias; a.amax = amax; a.out = out;
     a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha;
     const int lds = 2 * CV_STAGE_U4 * 16;
     static bool attr_set = false;

@@ -351,11 +351,12 @@ def pack_conv3x3_weight(weight):
 _conv_images = {}
 
 
-def conv3x3_fused(sources, ws, w_alpha, bias, bounds=None):
+def conv3x3_fused(sources, ws, w_alpha, bias, bounds=None, pixel_bias=None):
     """3x3 / stride 1 / pad 1 convolution of the channel concatenation of ``sources`` (NCHW fp32 tensors with
     equal N, H, W) -> [N, H, W, 256] fp32 channel-last.  absmax -> pack (NCHW fp32 -> padded channel-last f16
     hi/lo image) -> implicit-GEMM kernel; the padded image buffer is allocated (zeroed) once per shape.
-    ``bounds[i]``: a known upper bound of |sources[i]| (the source is then not scanned by the absmax pass)."""
+    ``bounds[i]``: a known upper bound of |sources[i]| (the source is then not scanned by the absmax pass).
+    ``pixel_bias``: [H*W, 256] additive map (per pixel and output channel, shared by the N images) instead of ``bias``."""
     _lib.require_gpu(*sources, ws, what="conv3x3_fused")
     N, _, H, W = sources[0].shape
     cin = sum(int(t.shape[1]) for t in sources)
@@ -384,7 +385,11 @@ def conv3x3_fused(sources, ws, w_alpha, bias, bounds=None):
                                        _lib.stream_ptr()), "rac_conv_pack_fwd")
         off += int(t.shape[1])
     out = torch.empty(N, H, W, 256, device=dev, dtype=torch.float32)
-    _lib.check(L.rac_conv3x3_fwd(_lib.ptr(xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None, _lib.ptr(amax),
+    if pixel_bias is not None and (tuple(pixel_bias.shape) != (H * W, 256) or not pixel_bias.is_contiguous()
+                                   or pixel_bias.dtype != torch.float32 or not pixel_bias.is_cuda):
+        raise RuntimeError("conv3x3_fused: pixel_bias must be a contiguous float32 CUDA [H*W, 256] tensor")
+    _lib.check(L.rac_conv3x3_fwd(_lib.ptr(xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None,
+                                 _lib.ptr(pixel_bias) if pixel_bias is not None else None, _lib.ptr(amax),
                                  float(w_alpha), _lib.ptr(out), N, H, W, cin, 256, _lib.stream_ptr()), "rac_conv3x3_fwd")
     if ev:
         ev[1].record()

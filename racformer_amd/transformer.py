@@ -359,13 +359,15 @@ class RadarBEVTemporalEncoder(nn.Module):
                 and self.temporal_fusion.kernel_size == (3, 3) and self.temporal_fusion.padding == (1, 1))
 
     def forward_channel_last(self, bev_feats, packed, hidden=None):
-        """-> [B*T, H, W, C] (channel-last).  ``packed`` = pack_conv3x3_weight(temporal_fusion.weight) + (hidden_bound(),);
-        ``hidden``: hidden_stream(bev_feats) if the caller already ran it (on a side stream)."""
+        """-> [B*T, H, W, C] (channel-last).  ``packed``: dict(ws, alpha = pack_conv3x3_weight(.), bound = hidden_bound(),
+        optional pixel_bias [H*W, C] replacing the convolution's bias); ``hidden``: hidden_stream(bev_feats) if the
+        caller already ran it (on a side stream)."""
         x, hid = hidden if hidden is not None else self.hidden_stream(bev_feats)
         # |ConvGRU state| <= 1 (convex combinations of tanh values, zero start), bilinear resizing keeps that, so
         # |hid| <= max_row ||W_up||_1 + max|b_up|: known from the weights, no need to scan the tensor
-        return conv3x3_fused([x.contiguous(), hid.contiguous()], packed[0], packed[1], self.temporal_fusion.bias,
-                             bounds=[None, packed[2]])
+        pb = packed.get("pixel_bias")
+        return conv3x3_fused([x.contiguous(), hid.contiguous()], packed["ws"], packed["alpha"],
+                             None if pb is not None else self.temporal_fusion.bias, bounds=[None, packed["bound"]], pixel_bias=pb)
 
 
 class BEVSelfAttention(nn.Module):
@@ -469,16 +471,39 @@ class BEVSampling(nn.Module):
     def prepare_value(self, bev_feats, conv_pack=None, hidden=None):
         """Query-independent half of inner_forward (:484-485, :532-537 + value_proj): temporal
         encoder (radar only), + learned positional encoding, value projection.  ``conv_pack``: the packed
-        temporal_fusion weights (fused convolution kernel, channel-last output) or None (MIOpen)."""
+        temporal_fusion weights (fused convolution kernel, channel-last output) or None (MIOpen).  With
+        ``conv_pack["pixel_bias"]`` the pack holds value_proj o temporal_fusion (composed_value_pack) and the
+        convolution's output IS the value stream."""
         H, W = bev_feats.shape[-2:]
+        if self.temp_radar and conv_pack is not None and conv_pack.get("ws") is not None and \
+                self.temporal_encoder.fused_conv_supported(bev_feats):
+            B, T = bev_feats.shape[:2]
+            nhwc = self.temporal_encoder.forward_channel_last(bev_feats, conv_pack, hidden() if callable(hidden) else hidden)
+            if conv_pack.get("pixel_bias") is not None:
+                return nhwc.view(B * T, H * W, self.attention.num_heads, -1), (H, W)
+            pos = self.positional_encoding.grid(H, W).to(bev_feats.dtype)
+            return self.attention.project_value(nhwc.view(B, T, H, W, -1), pos, channel_last=True), (H, W)
         pos = self.positional_encoding.grid(H, W).to(bev_feats.dtype)
         if self.temp_radar:
-            if conv_pack is not None and conv_pack[0] is not None and self.temporal_encoder.fused_conv_supported(bev_feats):
-                B, T = bev_feats.shape[:2]
-                nhwc = self.temporal_encoder.forward_channel_last(bev_feats, conv_pack, hidden() if callable(hidden) else hidden)
-                return self.attention.project_value(nhwc.view(B, T, H, W, -1), pos, channel_last=True), (H, W)
             bev_feats = self.temporal_encoder(bev_feats)
         return self.attention.project_value(bev_feats, pos), (H, W)
+
+    def composed_value_pack(self, H, W):
+        """value_proj(temporal_fusion(cat) + pos) is one linear map of the concatenated maps: the 3x3 convolution with
+        weights W' = W_v . W_conv (composed per tap) plus the per-pixel term P' = pos^T W_v^T + W_v b_conv + b_v.  Composing
+        them once per set of weights (float64, then fp32) removes the 17-GFLOP value projection of the radar stream and
+        its positional-term GEMM from every forward; the convolution kernel then writes the value stream
+        [B*T, H*W, heads, 64] directly.  -> dict(ws, alpha, bound, pixel_bias) for prepare_value, or {} if it cannot be packed."""
+        te, at = self.temporal_encoder, self.attention
+        wv, bv = at.value_proj.weight.detach().double(), at.value_proj.bias.detach().double()
+        wc = te.temporal_fusion.weight.detach().double()
+        bc = te.temporal_fusion.bias.detach().double() if te.temporal_fusion.bias is not None else wv.new_zeros(wc.shape[0])
+        ws, alpha = pack_conv3x3_weight(torch.einsum("oc,cikl->oikl", wv, wc).float())
+        if ws is None:
+            return {}
+        pos = self.positional_encoding.grid(H, W).detach().double().reshape(-1, H * W)            # [C, HW]
+        pixel_bias = (pos.t() @ wv.t() + (wv @ bc + bv)).float().contiguous()                          # [HW, C]
+        return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), pixel_bias=pixel_bias)
 
     def keypoints(self, query_ray, query_feat, time_diff, d_region):
         """-> loc [B,Q,heads,T,P,2] in [0,1], weights [B,Q,heads,T,1,P] (:490-529)."""
@@ -725,6 +750,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # K-concatenated images.  Measured 158 us against 130 us (8 K-steps per 256x256 tile: the two-stage register pipeline
         # of the convolution kernel does not hide the first-load and store latencies of so short a K loop), so it is off.
         self.own_gemm = False
+        # radar stream: value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack)
+        self.compose_radar_value = True
         self._pack_cache = {}
 
     def _cached(self, key, params, fn):
@@ -774,11 +801,22 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         """Layer-invariant tensors (computed once per forward).  ``radar_hidden``: a callable returning
         temporal_encoder.hidden_stream(radar_bev_feats) computed elsewhere (it is called right before the result is
         needed, i.e. after the LSS value stream has been enqueued)."""
-        te = self.sampling_radar_bev.temporal_encoder
-        up = te.upsample[1]
-        conv_pack = self._cached("conv_pack", [te.temporal_fusion.weight, up.weight] + ([up.bias] if up.bias is not None else []),
-                                 lambda: pack_conv3x3_weight(te.temporal_fusion.weight) + (te.hidden_bound(),)) \
-            if radar_bev_feats.is_cuda and self.fused and te.fused_conv else None
+        rbs = self.sampling_radar_bev
+        te, up = rbs.temporal_encoder, rbs.temporal_encoder.upsample[1]
+        conv_pack = None
+        if radar_bev_feats.is_cuda and self.fused and te.fused_conv:
+            Hr, Wr = radar_bev_feats.shape[-2:]
+            conv_params = [te.temporal_fusion.weight, up.weight] + [m.bias for m in (te.temporal_fusion, up) if m.bias is not None]
+            if self.compose_radar_value:
+                pe_, vp = rbs.positional_encoding, rbs.attention.value_proj
+                conv_pack = self._cached(f"conv_value_pack_{Hr}x{Wr}", conv_params + [vp.weight, vp.bias, pe_.row_embed.weight,
+                                                                                     pe_.col_embed.weight],
+                                         lambda: rbs.composed_value_pack(Hr, Wr))
+            if not conv_pack:
+                def plain_pack():
+                    ws, alpha = pack_conv3x3_weight(te.temporal_fusion.weight)
+                    return dict(ws=ws, alpha=alpha, bound=te.hidden_bound())
+                conv_pack = self._cached("conv_pack", conv_params, plain_pack)
         lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
         radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack, radar_hidden)
         rb, lb, mix = self.sampling_radar_bev, self.sampling_lss_bev, self.mixing

@@ -314,7 +314,8 @@ def test_temporal_encoder_fused_pieces():
     with torch.no_grad():
         ref = enc(bev)                                                     # CPU: the reference decomposition
         eg = enc.to(DEV)
-        got = eg.forward_channel_last(bev.to(DEV), pack_conv3x3_weight(eg.temporal_fusion.weight) + (eg.hidden_bound(),))
+        ws, alpha = pack_conv3x3_weight(eg.temporal_fusion.weight)
+        got = eg.forward_channel_last(bev.to(DEV), dict(ws=ws, alpha=alpha, bound=eg.hidden_bound()))
     assert (got.permute(0, 3, 1, 2).cpu() - ref[0]).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
 
 
@@ -402,3 +403,21 @@ def test_gemm_f16x3_kernel(M):
     e_own = (got.double() - want).abs().max().item()
     e_fp32 = (lin(x).double() - want).abs().max().item()
     assert e_own < 4 * e_fp32 + 1e-6, (e_own, e_fp32)
+
+
+def test_composed_radar_value_stream():
+    """value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack, per-pixel bias in the
+    convolution's epilogue) against the sequential evaluation temporal_encoder -> + pos -> value_proj."""
+    from racformer_amd.transformer import BEVSampling
+    torch.manual_seed(13)
+    bs = BEVSampling(256, num_frames=8, num_points=4, num_heads=4, num_levels=1, pc_range=list(syn.PC_RANGE), depth_num=5,
+                     spatial_shapes=(16, 16), temp_radar=True).eval()
+    torch.nn.init.normal_(bs.temporal_encoder.temporal_fusion.bias, std=0.1)
+    torch.nn.init.normal_(bs.attention.value_proj.bias, std=0.1)
+    bev = torch.randn(1, 8, 256, 16, 16) * 0.7
+    with torch.no_grad():
+        want, _ = bs.prepare_value(bev)                       # CPU: MIOpen-free sequential reference
+        bg = bs.to(DEV)
+        got, hw = bg.prepare_value(bev.to(DEV), bg.composed_value_pack(16, 16))
+    assert hw == (16, 16) and tuple(got.shape) == tuple(want.shape)
+    assert (got.cpu() - want).abs().max().item() < 2e-5 * want.abs().max().item() + 1e-5

@@ -32,6 +32,8 @@
  *                        models/racformer_transformer.py:589-603
  *   rac_sasa_fwd      <- ScaleAdaptiveSelfAttention.inner_forward's mask + attention product
  *                        models/racformer_transformer.py:296-335
+ *   rac_decode_fwd    <- NMSFreeCoder.decode_single + get_bboxes, models/bbox/coders/nms_free_coder.py:37-88,
+ *                        models/racformer_head.py:488-507
  *   rac_gemm_f16x3_fwd <- AdaptiveMixing.parameter_generator (nn.Linear 256 -> 65536), models/racformer_transformer.py:565,589
  *   rac_rowgemm_fwd   <- nn.Linear + its preceding add / LayerNorm / ReLU groups, models/racformer_transformer.py:170-177, 243-269
  *   rac_gru_gate_fwd / rac_upsample2x_fwd <- ConvGRUCell.forward's element-wise tail, nn.Upsample
@@ -283,6 +285,16 @@ int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream);
  *   out   : device f32, row stride ld_out;  N % 256 == 0, K % 32 == 0 */
 int rac_gemm_f16x3_fwd(const void *a_img, const void *w_img, const float *bias, float alpha, float *out, int ld_out, int M,
                        int N, int K, void *stream);
+
+/* NMS-free decode of one sample in one launch: sigmoid, top-max_num of the num_query x num_classes scores (sorted by
+ * score, ties by flat index), label = idx % C, query = idx / C, denormalize_bbox (exp of the log sizes, atan2 of sin / cos),
+ * centre-range and score masks, z moved to the box bottom.  Replaces NMSFreeCoder.decode_single + the reshuffle of
+ * get_bboxes (models/bbox/coders/nms_free_coder.py:37-88, models/bbox/utils.py:26-46, models/racformer_head.py:488-507).
+ *   cls_scores [Q,C] logits, bbox_preds [Q,10] = (cx, cy, log w, log l, cz, log h, sin, cos, vx, vy) of the last layer
+ *   out [max_num,11] = (x, y, z_bottom, w, l, h, yaw, vx, vy, score, label); masked rows carry score = -1
+ *   post_center_range: HOST (6);  Q*C <= 16384, max_num <= 512 */
+int rac_decode_fwd(const float *cls_scores, const float *bbox_preds, float *out, int num_query, int num_classes,
+                   int max_num, const float *post_center_range, float score_threshold, int use_threshold, void *stream);
 
 /* Backward of the two gather operators (SURVEY.md section 8 "next" row f4; fp32 features only).
  * rac_msmv_bwd  <- _ms_deform_attn_cuda_{c45,c2345,c23456}_backward, models/csrc/msmv_sampling/msmv_sampling.cpp:302-497

@@ -35,6 +35,7 @@ SIGNATURES = {
     "rac_refine_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_f, _vp]),
     "rac_mixing_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _f] + [_i] * 6 + [_f, _i, _vp]),
     "rac_sasa_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
+    "rac_decode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _i, _vp]),
     "rac_gemm_f16x3_fwd": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "rac_rowgemm_fwd": (_i, [_vp, _i, _i, _vp]),
     "rac_gru_gate_fwd": (_i, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i, _i, _i, _vp]),

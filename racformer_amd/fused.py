@@ -540,3 +540,20 @@ def gemm_f16x3(a_img, w_img, bias, alpha):
                                        float(alpha), _lib.ptr(out), N, M, N, chunks * 32, _lib.stream_ptr())
     _lib.check(rc, "rac_gemm_f16x3_fwd")
     return out
+
+
+# ------------------------------------------------------------------------------------------- decode
+def decode_fused(cls_scores, bbox_preds, max_num, post_center_range, score_threshold=None, out=None):
+    """NMSFreeCoder.decode_single + get_bboxes' reshuffle for one sample in one launch (rac_decode_fwd):
+    cls_scores [Q,C] logits, bbox_preds [Q,10] -> [max_num, 11] = (x, y, z_bottom, w, l, h, yaw, vx, vy, score, label),
+    score = -1 on rows that fail the centre-range / score masks."""
+    cls_scores, bbox_preds = cls_scores.contiguous(), bbox_preds.contiguous()
+    _lib.require_gpu(cls_scores, bbox_preds, what="decode_fused")
+    Q, C = cls_scores.shape
+    if out is None:
+        out = torch.empty(max_num, 11, device=cls_scores.device, dtype=torch.float32)
+    rng = (ctypes.c_float * 6)(*[float(v) for v in post_center_range])
+    rc = _lib.lib().rac_decode_fwd(_lib.ptr(cls_scores), _lib.ptr(bbox_preds), _lib.ptr(out), Q, C, int(max_num), rng,
+                                   float(score_threshold or 0.0), int(bool(score_threshold)), _lib.stream_ptr())
+    _lib.check(rc, "rac_decode_fwd")
+    return out

@@ -393,7 +393,7 @@ class BEVSelfAttention(nn.Module):
             nn.init.xavier_uniform_(m.weight)
             nn.init.constant_(m.bias, 0.0)
 
-    def project_value(self, value_maps, pos=None, channel_last=False):
+    def project_value(self, value_maps, pos=None, channel_last=False, pos_term=None):
         """value_maps [B,T,C,H,W] ([B,T,H,W,C] with channel_last) (+ optional positional map [C,H,W] added to every frame) ->
         [B*T, H*W, heads, C/heads] (bev_self_attention.py:162-174).  Query-independent: the decoder
         calls this once per forward, not once per layer.  value_proj is linear, so
@@ -405,7 +405,9 @@ class BEVSelfAttention(nn.Module):
         else:
             B, T, C, H, W = value_maps.shape
         wt = self.value_proj.weight.t()
-        if pos is None:
+        if pos_term is not None:       # value_proj(pos) [H*W, C] precomputed by the caller (depends on weights only)
+            bias = pos_term.unsqueeze(0).expand(B * T, H * W, C)
+        elif pos is None:
             bias = self.value_proj.bias.view(1, 1, C).expand(B * T, H * W, C)
         else:
             bias = self.value_proj(pos.reshape(C, H * W).t()).unsqueeze(0).expand(B * T, H * W, C)
@@ -817,7 +819,16 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
                     ws, alpha = pack_conv3x3_weight(te.temporal_fusion.weight)
                     return dict(ws=ws, alpha=alpha, bound=te.hidden_bound())
                 conv_pack = self._cached("conv_pack", conv_params, plain_pack)
-        lss_value, lss_hw = self.sampling_lss_bev.prepare_value(lss_bev_feats)
+        lbs = self.sampling_lss_bev
+        if lss_bev_feats.is_cuda and self.fused:
+            # the positional term value_proj(pos) of the LSS stream depends on weights only: built once, not per forward
+            Hl, Wl = lss_bev_feats.shape[-2:]
+            lvp, lpe = lbs.attention.value_proj, lbs.positional_encoding
+            pos_term = self._cached(f"lss_pos_term_{Hl}x{Wl}", [lvp.weight, lvp.bias, lpe.row_embed.weight, lpe.col_embed.weight],
+                                    lambda: lvp(lpe.grid(Hl, Wl).to(lvp.weight.dtype).reshape(-1, Hl * Wl).t()).contiguous())
+            lss_value, lss_hw = lbs.attention.project_value(lss_bev_feats, pos_term=pos_term), (Hl, Wl)
+        else:
+            lss_value, lss_hw = lbs.prepare_value(lss_bev_feats)
         radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack, radar_hidden)
         rb, lb, mix = self.sampling_radar_bev, self.sampling_lss_bev, self.mixing
         wide_mods = [self.sampling.sampling_offset, self.sampling.ray_points_offset, self.sampling.scale_weights]

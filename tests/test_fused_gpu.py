@@ -421,3 +421,32 @@ def test_composed_radar_value_stream():
         got, hw = bg.prepare_value(bev.to(DEV), bg.composed_value_pack(16, 16))
     assert hw == (16, 16) and tuple(got.shape) == tuple(want.shape)
     assert (got.cpu() - want).abs().max().item() < 2e-5 * want.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("Q,C,K", [(900, 10, 300), (20, 10, 300), (1600, 10, 512), (7, 3, 5)])
+def test_decode_kernel_matches_torch_decode(Q, C, K):
+    """rac_decode_fwd (radix-select top-K + denormalise + masks, one launch) against the torch formulation of
+    NMSFreeCoder.topk_fixed / get_detections_fixed on the CPU, incl. K > Q*C and exact score ties."""
+    from racformer_amd.head import NMSFreeCoder
+    from racformer_amd.fused import decode_fused
+    torch.manual_seed(Q + K)
+    coder = NMSFreeCoder(pc_range=list(syn.PC_RANGE), post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_num=K,
+                         score_threshold=0.3, num_classes=C)
+    cls = torch.randn(Q, C) * 2.0
+    cls[3 % Q, 1] = cls[5 % Q, 2] = 4.25            # an exact tie near the top
+    box = torch.randn(Q, 10)
+    box[:, 0:2] *= 40.0                                # some centres outside the post-centre range
+    got = decode_fused(cls.to(DEV), box.to(DEV), K, coder.post_center_range, coder.score_threshold).cpu()
+    n = min(K, Q * C)
+    k_eff = coder.max_num = n                          # torch.topk cannot ask for more than Q*C
+    b, s, l, keep = coder.topk_fixed(cls, box)
+    b = torch.cat([b[:, :2], b[:, 2:3] - b[:, 5:6] * 0.5, b[:, 3:]], dim=1)
+    s = torch.where(keep, s, torch.full_like(s, -1.0))
+    want = torch.cat([b, s[:, None], l[:, None].float()], dim=1)
+    # rows are sorted by score; tied scores may come in either order: compare as sets of rows keyed by (query, label)
+    raw = torch.sigmoid(cls).view(-1).topk(k_eff)[0]
+    assert torch.allclose(torch.where(got[:n, 9] >= 0, got[:n, 9], raw), raw, atol=1e-6)      # descending score order
+    d = (got[:n, None, :].double() - want[None, :n, :].double()).abs().amax(-1)                # every row has its twin
+    assert d.min(1).values.max().item() < 1e-4 and d.min(0).values.max().item() < 1e-4
+    if K > n:
+        assert bool((got[n:, 9] == -1).all())

@@ -5,9 +5,9 @@
 // sort, gathers, exp / atan2, comparisons, concatenations).  Shape-static output [K][11] = (x, y, z_bottom, w, l, h, yaw,
 // vx, vy, score, label); rows that fail the masks carry score = -1 (the data-parallel wire format).
 //
-// One workgroup of 1024 threads.  Top-K by radix select on 64-bit keys (order-preserving bits of the logit, then the
+// One workgroup of 1024 threads.  Top-K by radix select on 48-bit keys (order-preserving bits of the logit, then the
 // inverted flat index: all keys distinct, ties resolve to the smaller index, the result is deterministic), 8 bits per pass
-// on a 256-bin LDS histogram; the K survivors are sorted descending by a bitonic network in LDS.  sigmoid is monotonic, so
+// on a 256-bin LDS histogram whose suffix sums are scanned in parallel; the K survivors are ordered by rank counting.  sigmoid is monotonic, so
 // selection runs on the logits and only K sigmoids are evaluated.
 #include "rac_common.h"
 
@@ -32,7 +32,7 @@ __device__ __forceinline__ unsigned dec_sortable(float v)
 
 __global__ __launch_bounds__(DEC_THREADS) void decode_topk_kernel(const DecArgs a)
 {
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[256], scan[256];
     __shared__ unsigned long long sel[DEC_MAX_K];
     __shared__ unsigned long long s_prefix, s_mask;
     __shared__ int s_remaining, s_count;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_topk_kernel(const DecArgs 
         const int i = tid + DEC_THREADS * j;
         key[j] = 0ull;   // below every real key (real keys have a non-zero high word unless the logit is -NaN-like)
         if (i < n)
-            key[j] = ((unsigned long long)dec_sortable(a.cls[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            key[j] = ((unsigned long long)dec_sortable(a.cls[i]) << 16) | (unsigned long long)(0xFFFFu - (unsigned)i);
     }
     if (tid == 0) {
         s_prefix = 0ull;
@@ -54,28 +54,37 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_topk_kernel(const DecArgs 
         s_count = 0;
     }
     __syncthreads();
-    // radix select of the K-th largest key: 8 passes of 8 bits, most significant first
-    for (int shift = 56; shift >= 0; shift -= 8) {
+    // radix select of the K-th largest key: 6 passes of 8 bits, most significant first
+    for (int shift = 40; shift >= 0; shift -= 8) {
         if (tid < 256)
             hist[tid] = 0u;
         __syncthreads();
         const unsigned long long prefix = s_prefix, mask = s_mask;
+        const int remaining = s_remaining;
 #pragma unroll
         for (int j = 0; j < DEC_MAX_PER_THREAD; ++j)
             if (tid + DEC_THREADS * j < n && (key[j] & mask) == prefix)
                 atomicAdd(&hist[(unsigned)(key[j] >> shift) & 255u], 1u);
         __syncthreads();
-        if (tid == 0) {
-            int remaining = s_remaining, b = 255;
-            unsigned cum = 0;
-            for (; b > 0; --b) {
-                if (cum + hist[b] >= (unsigned)remaining)
-                    break;
-                cum += hist[b];
+        // suffix sums S[b] = sum_{c >= b} hist[c] (Hillis-Steele over 256 bins, threads 0..255); the selected bin is the
+        // largest b with S[b] >= remaining, i.e. S[b] >= remaining > S[b+1]
+        if (tid < 256)
+            scan[tid] = hist[tid];
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const unsigned add = (tid < 256 && tid + off < 256) ? scan[tid + off] : 0u;
+            __syncthreads();
+            if (tid < 256)
+                scan[tid] += add;
+            __syncthreads();
+        }
+        if (tid < 256) {
+            const unsigned sb = scan[tid], sn = tid + 1 < 256 ? scan[tid + 1] : 0u;
+            if ((sb >= (unsigned)remaining && sn < (unsigned)remaining) || (tid == 0 && sb < (unsigned)remaining)) {
+                s_remaining = remaining - (int)sn;      // (tid 0 with too few candidates: everything is selected)
+                s_prefix = prefix | ((unsigned long long)tid << shift);
+                s_mask = mask | (0xFFull << shift);
             }
-            s_remaining = remaining - (int)cum;
-            s_prefix = prefix | ((unsigned long long)b << shift);
-            s_mask = mask | (0xFFull << shift);
         }
         __syncthreads();
     }
@@ -91,25 +100,26 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_topk_kernel(const DecArgs 
                 sel[pos] = key[j];
         }
     __syncthreads();
-    // bitonic sort of the 512-entry buffer, descending (unused entries are 0 and sink to the end)
-    for (int k2 = 2; k2 <= DEC_MAX_K; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            if (tid < DEC_MAX_K) {
-                const int partner = tid ^ j2;
-                if (partner > tid) {
-                    const unsigned long long x = sel[tid], y = sel[partner];
-                    const bool desc = (tid & k2) == 0;
-                    if (desc ? x < y : x > y) {
-                        sel[tid] = y;
-                        sel[partner] = x;
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    // order by rank counting: the rank of a survivor is the number of survivors with a larger key (keys are distinct)
+    const int nsel = min(s_count, DEC_MAX_K);
+    unsigned long long mykey = 0ull;
+    int rank = -1;
+    if (tid < nsel) {
+        mykey = sel[tid];
+        rank = 0;
+        for (int i = 0; i < nsel; ++i)
+            rank += sel[i] > mykey ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < DEC_MAX_K)
+        sel[tid] = 0ull;
+    __syncthreads();
+    if (rank >= 0)
+        sel[rank] = mykey;
+    __syncthreads();
     if (tid < a.K) {
         const unsigned long long kk = sel[tid];
-        const int idx = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+        const int idx = (int)(0xFFFFu - (unsigned)(kk & 0xFFFFull));
         float *o = a.out + (size_t)tid * 11;
         if (kk == 0ull || idx < 0 || idx >= n) {   // fewer than K candidates (K > Q*C): empty row
 #pragma unroll

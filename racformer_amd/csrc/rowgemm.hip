@@ -35,7 +35,10 @@ __device__ __forceinline__ float rg_wave_sum(float v)
 
 // NSEG: 256-wide segments of K.  MT: 16-row tiles per workgroup (1: 16 rows, all CUs busy at N = 256; 4: 64 rows, the
 // weight fragments of a wave are reused by four row tiles -- a quarter of the L2 weight traffic, for the wide layers).
-template <int NSEG, int MT>
+// EARLY: issue the first segment's weight loads above the prologue (best for the 228-workgroup launches, where one
+// workgroup per CU has to hide its own latencies); without it the kernel fits 128 VGPRs = 4 workgroups per CU, which is what
+// the wide layers (up to 1995 workgroups) need.
+template <int NSEG, int MT, bool EARLY>
 __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, float *sX)
 {
     constexpr int K = 256 * NSEG, LD = K + 4, R = 16 * MT;
@@ -52,9 +55,11 @@ __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, flo
     const float *bp = d.w + (size_t)wrow * K + 4 * lk;
     const int rot = (blockIdx.x * 5) & 15;
     rac_f4 bcur[16], bnxt[16];
+    if (EARLY) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
-        bcur[u] = rac_ld4(bp + 16 * ((u + rot) & 15));
+        for (int u = 0; u < 16; ++u)
+            bcur[u] = rac_ld4(bp + 16 * ((u + rot) & 15));
+    }
 
     // ---- prologue: build the R x K activation tile (wave w: rows w*R/4 .., 4 at a time; lane: 4 columns per segment) ----
 #pragma unroll
@@ -157,6 +162,11 @@ __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, flo
     // weights of one 256-wide segment = 16 loads of 16 bytes per lane, all issued before the segment's MFMAs; the
     // next segment's loads are issued before the current segment's MFMAs (one memory latency per launch, not per step)
     const float *ap = sX + li * LD + 4 * lk;
+    if (!EARLY) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            bcur[u] = rac_ld4(bp + 16 * ((u + rot) & 15));
+    }
     rg_f4 acc[MT][2];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -201,14 +211,14 @@ __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, flo
         }
 }
 
-template <int NSEG, int MT>
-__global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs a)
+template <int NSEG, int MT, bool EARLY>
+__global__ __launch_bounds__(256, EARLY ? 2 : 4) void rowgemm_kernel(const RowGemmArgs a)
 {
     extern __shared__ float smem[];
     const rac_rowgemm &d = a.d[blockIdx.z];
     if ((int)blockIdx.y * 64 >= d.N)
         return;   // (uniform per workgroup: batched GEMMs may have different widths)
-    rowgemm_body<NSEG, MT>(d, a.rows, smem);
+    rowgemm_body<NSEG, MT, EARLY>(d, a.rows, smem);
 }
 
 extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream)
@@ -249,17 +259,19 @@ extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void
     if (MT == 4) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<1, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((rowgemm_kernel<1, 4>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((rowgemm_kernel<1, 4, true>), grid, dim3(256), lds, st, a);
     } else if (MT == 2)
-        hipLaunchKernelGGL((rowgemm_kernel<1, 2>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((rowgemm_kernel<1, 2, true>), grid, dim3(256), lds, st, a);
+    else if (max_seg == 1 && (long)grid.x * grid.y * grid.z > 512)
+        hipLaunchKernelGGL((rowgemm_kernel<1, 1, false>), grid, dim3(256), lds, st, a);   // many workgroups: occupancy first
     else if (max_seg == 1)
-        hipLaunchKernelGGL((rowgemm_kernel<1, 1>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((rowgemm_kernel<1, 1, true>), grid, dim3(256), lds, st, a);
     else if (max_seg == 2)
-        hipLaunchKernelGGL((rowgemm_kernel<2, 1>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((rowgemm_kernel<2, 1, true>), grid, dim3(256), lds, st, a);
     else
-        hipLaunchKernelGGL((rowgemm_kernel<3, 1>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((rowgemm_kernel<3, 1, true>), grid, dim3(256), lds, st, a);
     return rac_launch_status("rac_rowgemm_fwd");
 }

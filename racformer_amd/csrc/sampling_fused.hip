@@ -12,7 +12,7 @@
 // (optionally also written out for parity debugging, the counterpart of the reference's DUMP
 // hooks, sparsebev_sampling.py:83-87).
 //
-// Workgroup = 4 waves = 4 consecutive queries of one slot (b,t,g).  Phase 1: the first 4*P threads
+// Workgroup = 4 waves = S4D_ROWS consecutive queries of one slot (b,t,g).  Phase 1: the first S4D_ROWS*P threads
 // compute one keypoint each (box decode, offset, yaw rotation, velocity warp, polar jitter,
 // projection into the N cameras of frame t, first valid view, softmax over levels) into LDS.
 // Phase 2: identical to msmv_fwd_c64_kernel -- 16-lane group per point, 16-byte loads, 16 taps in
@@ -24,7 +24,9 @@
 // (sparsebev_sampling.py:113-120, quirk Q1).
 #include "rac_common.h"
 
-#define S4D_ROWS 4
+#ifndef S4D_ROWS
+#define S4D_ROWS 16 /* queries per workgroup: one prologue pass (up to 192 keypoints on 192 threads) serves 4 gather rounds */
+#endif
 #ifndef S4D_LB
 #define S4D_LB 4 /* levels per load batch (see the gather loop) */
 #endif
@@ -179,17 +181,18 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
         }
     }
     __syncthreads();
-    if (wave >= nrows)
-        return;
-    const int q = q0 + wave;
+    // wave w gathers rows w, w+4, ... of the workgroup's S4D_ROWS queries: the keypoint prologue above (one pass, its
+    // latency independent of the number of keypoints up to 256) is paid once per S4D_ROWS / 4 gather rounds
+    for (int row = wave; row < nrows; row += 4) {
+    const int q = q0 + row;
     const size_t out_row = ((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * (size_t)P * 64;
 
     for (int p0 = 0; p0 < P; p0 += 4) {
         const int p = p0 + sub;
         const bool act = p < P;
         const int pp = act ? p : P - 1;
-        const float *lp = sloc + (wave * P + pp) * 3;
-        const float *wp = sw + (wave * P + pp) * L;
+        const float *lp = sloc + (row * P + pp) * 3;
+        const float *wp = sw + (row * P + pp) * L;
         const float lu = lp[0], lv = lp[1];
         const int view = (int)lp[2];
 
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
         }
         if (act)
             *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = acc;
+    }
     }
 }
 

@@ -23,6 +23,7 @@
 // slot s are read from the (b,g',t') flattening at s' = t*G+g, g' = s'/T, t' = s'%T
 // (sparsebev_sampling.py:113-120, quirk Q1).
 #include "rac_common.h"
+#include <stdlib.h>
 
 #ifndef S4D_ROWS
 #define S4D_ROWS 16 /* queries per workgroup: one prologue pass (up to 192 keypoints on 192 threads) serves 4 gather rounds */
@@ -56,6 +57,7 @@ struct S4dArgs {
     int L, B, T, N, G, Q, NP, D, P;
     int ld_off, ld_ray, ld_scale;  // row strides (floats) of off / ray / scale: slices of one fused GEMM output
     int blocks_per_slot;
+    int rows;  // queries per workgroup (S4D_ROWS unless overridden for experiments)
 };
 
 #define S4D_TWO_PI 6.283185307179586f
@@ -156,13 +158,13 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
     const int s = xcd + 8 * (j / a.blocks_per_slot);
     if (s >= S)
         return;
-    const int q0 = (j % a.blocks_per_slot) * S4D_ROWS;
-    const int nrows = min(S4D_ROWS, a.Q - q0);
+    const int q0 = (j % a.blocks_per_slot) * a.rows;
+    const int nrows = min(a.rows, a.Q - q0);
     const int g = s % a.G, t = (s / a.G) % a.T, b = s / (a.G * a.T);
 
     float *sloc = smem;                     // [rows][P][3]
-    float *sw = sloc + S4D_ROWS * P * 3;    // [rows][P][L]
-    float *sl2i = sw + S4D_ROWS * P * L;    // [N][16]
+    float *sw = sloc + a.rows * P * 3;      // [rows][P][L]
+    float *sl2i = sw + a.rows * P * L;      // [N][16]
     for (int i = tid; i < a.N * 16; i += 256)
         sl2i[i] = a.l2i[((size_t)b * a.T + t) * a.N * 16 + i];
     __syncthreads();
@@ -292,10 +294,12 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
     a.d_region = d_region; a.image_h = image_h; a.image_w = image_w; a.eps = eps;
     a.L = L; a.B = B; a.T = T; a.N = N; a.G = G; a.Q = Q; a.NP = NP; a.D = D; a.P = P;
     a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale;
-    a.blocks_per_slot = (Q + S4D_ROWS - 1) / S4D_ROWS;
+    static const int rows_env = getenv("RAC_S4D_ROWS") ? atoi(getenv("RAC_S4D_ROWS")) : 0;
+    a.rows = rows_env >= 4 && rows_env <= 64 && rows_env % 4 == 0 ? rows_env : S4D_ROWS;
+    a.blocks_per_slot = (Q + a.rows - 1) / a.rows;
     const int S = B * T * G;
     const int nb = 8 * ((S + 7) / 8) * a.blocks_per_slot;
-    const size_t lds = ((size_t)S4D_ROWS * P * (3 + L) + (size_t)N * 16) * sizeof(float);
+    const size_t lds = ((size_t)a.rows * P * (3 + L) + (size_t)N * 16) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define S4D_LAUNCH(FT, LL) hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL>), dim3(nb), dim3(256), lds, st, a)
     if (dtype == RAC_F32) {

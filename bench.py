@@ -211,7 +211,7 @@ def main():
             ("mixing_out_proj_gemm", "out_proj split-K batched GEMM (hipBLASLt f16, K-concatenated hi/lo operands)" if split
              else "out_proj split-K batched GEMM (rocBLAS fp32)",
              2.0 * Qn * (G_ * 128 * C_) * E, 2.0 * Qn * (G_ * 128 * C_) * E * (3 if split else 1), PEAK16 if split else PEAK32),
-            ("temporal_fusion_conv", "conv3x3_f16x3_kernel (hand-written implicit GEMM, 3 f16 products) + absmax + pack",
+            ("temporal_fusion_conv", "conv3x3_f16x3_kernel (hand-written implicit GEMM, 3 f16 products; value_proj composed in)",
              2.0 * cfg.num_frames * bev_h * bev_w * 256 * 320 * 9, 3 * 2.0 * cfg.num_frames * bev_h * bev_w * 256 * 320 * 9, PEAK16)):
         ms = timer.mean_ms(key)
         if ms:

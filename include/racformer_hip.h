@@ -277,6 +277,12 @@ typedef struct {
 } rac_rowgemm;
 int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream);
 
+/* The downsample convolution of RadarBEVTemporalEncoder (3x3, stride 2, pad 1, Cin -> 64; models/racformer_transformer.py:632,646)
+ * on the activation image of rac_conv_pack_fwd (its first Cin channels; the image holds Cin_image >= Cin channels) with the
+ * arithmetic of rac_conv3x3_fwd.  ws = f16 [9 taps][Cin/32][64][2][32];  out [N,64,H/2,W/2] f32 (NCHW);  (H/2)*(W/2) % 256 == 0. */
+int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out, int N,
+                      int H, int W, int Cin, int Cin_image, int Cout, void *stream);
+
 /* Split-precision GEMM on the f16 matrix cores (3 products, fp32 accumulate, fp32-GEMM accuracy; hand-written, same inner
  * loop as rac_conv3x3_fwd):  out[M][N] = alpha * (A @ W^T) + bias.  Replaces the nn.Linear `parameter_generator` of
  * AdaptiveMixing (models/racformer_transformer.py:565,589).

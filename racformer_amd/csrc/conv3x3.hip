@@ -237,6 +237,123 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ conv, stride 2, 64 channels
+// The downsample convolution of the temporal encoder (3x3, stride 2, pad 1, 256 -> 64; models/racformer_transformer.py:632,
+// 646) on the same activation image (its first Cin/32 chunks; the image may carry more channels: chunks_total) and the
+// same arithmetic.  Tile = 256 consecutive output pixels of one image x 64 output channels; 8 waves along the pixels, each
+// 32 pixels x 64 channels (2 x 4 MFMA tiles); output NCHW f32 (what the ConvGRU's library convolutions read).
+struct ConvS2Args {
+    const uint4 *xs;
+    const uint4 *ws;      // [9][chunks][64][hi 32 | lo 32]
+    const float *bias;
+    const float *amax;
+    float *out;           // [N][64][OH][OW]
+    int N, H, W, chunks, chunks_total;
+    float w_alpha;
+};
+
+__global__ __launch_bounds__(512, 1) void conv3x3s2_c64_f16x3_kernel(const ConvS2Args a)
+{
+    extern __shared__ uint4 lds4[];
+    constexpr int STAGE = 2048 + 512;   // uint4 per LDS stage: A 256 rows, B 64 rows
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int H = a.H, W = a.W, Wp = W + 2, OH = H >> 1, OW = W >> 1, chunks = a.chunks;
+    const int tiles_per_img = (OH * OW) / CV_TM;
+    const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
+    const int KS = 9 * chunks;
+    const size_t pix_stride = (size_t)a.chunks_total * 8;
+    auto row_base = [&](int j) -> size_t {
+        const int r = (tid >> 3) + 64 * j;
+        const int gp = tile * CV_TM + r, oh = gp / OW, ow = gp - oh * OW;
+        return (((size_t)n * (H + 2) + 2 * oh) * Wp + 2 * ow) * pix_stride + (tid & 7);
+    };
+    auto row_slot = [&](int j) -> int {
+        const int r = (tid >> 3) + 64 * j;
+        return r * 8 + ((tid & 7) ^ ((r >> 1) & 7));
+    };
+    const size_t a_base0 = row_base(0), a_base1 = row_base(1), a_base2 = row_base(2), a_base3 = row_base(3);
+    const int st0 = row_slot(0), st1 = row_slot(1), st2 = row_slot(2), st3 = row_slot(3);
+    uint4 ra0, ra1, ra2, ra3, rb0;
+#define S2_GLOAD(ks_)                                                                          \
+    do {                                                                                       \
+        const int tap_ = (ks_) / chunks, chunk_ = (ks_) - tap_ * chunks;                       \
+        const int dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;                                        \
+        const size_t off_ = ((size_t)dy_ * Wp + dx_) * pix_stride + (size_t)chunk_ * 8;        \
+        ra0 = a.xs[a_base0 + off_]; ra1 = a.xs[a_base1 + off_];                                \
+        ra2 = a.xs[a_base2 + off_]; ra3 = a.xs[a_base3 + off_];                                \
+        rb0 = a.ws[(size_t)(ks_) * 512 + tid];                                                 \
+    } while (0)
+#define S2_LSTORE(buf_)                                                                        \
+    do {                                                                                       \
+        uint4 *A_ = lds4 + (buf_) * STAGE, *B_ = A_ + 2048;                                    \
+        A_[st0] = ra0; A_[st1] = ra1; A_[st2] = ra2; A_[st3] = ra3;                            \
+        B_[st0] = rb0;                                                                         \
+    } while (0)
+
+    cv_f4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+            acc[m][nn] = (cv_f4){0.f, 0.f, 0.f, 0.f};
+    int bidx_h[4], bidx_l[4];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+        const int row = 16 * nn + li, f = (row >> 1) & 7;
+        bidx_h[nn] = 2048 + row * 8 + (lk ^ f);
+        bidx_l[nn] = 2048 + row * 8 + ((4 + lk) ^ f);
+    }
+    const int arow0 = 32 * wave + li;
+
+    S2_GLOAD(0);
+    S2_LSTORE(0);
+    S2_GLOAD(KS > 1 ? 1 : 0);
+    __syncthreads();
+    for (int ks = 0; ks < KS; ++ks) {
+        S2_LSTORE((ks + 1) & 1);
+        const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
+        S2_GLOAD(kn);
+        const cv_h8 *S = reinterpret_cast<const cv_h8 *>(lds4 + (ks & 1) * STAGE);
+        cv_h8 bh[4], bl[4];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            bh[nn] = S[bidx_h[nn]];
+            bl[nn] = S[bidx_l[nn]];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = arow0 + 16 * m, f = (row >> 1) & 7;
+            const cv_h8 ah = S[row * 8 + (lk ^ f)];
+            const cv_h8 al = S[row * 8 + ((4 + lk) ^ f)];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nn], acc[m][nn], 0, 0, 0);
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nn], acc[m][nn], 0, 0, 0);
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nn], acc[m][nn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: NCHW store -- for a channel (column li) the lane's 4 accumulator rows are 4 consecutive output pixels
+    const float unscale = a.w_alpha / cv_act_scale(*a.amax);
+    float *obase = a.out + (size_t)n * 64 * OH * OW + (size_t)tile * CV_TM;
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+        const int co = 16 * nn + li;
+        const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int p = 32 * wave + 16 * m + 4 * lk;
+            rac_f4 o = {acc[m][nn][0] * unscale + bv, acc[m][nn][1] * unscale + bv, acc[m][nn][2] * unscale + bv,
+                        acc[m][nn][3] * unscale + bv};
+            *reinterpret_cast<rac_f4 *>(obase + (size_t)co * OH * OW + p) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ GEMM
 // The same inner loop as a plain split-precision GEMM  out[M][N] = alpha * (A @ W^T) + bias  (the convolution with one
 // tap): A image [M][K/32][hi 32 | lo 32] f16 (written by rac_rowgemm_fwd), W image [K/32][N][hi 32 | lo 32] f16 (packed
@@ -444,4 +561,29 @@ extern "C" int rac_gemm_f16x3_fwd(const void *a_img, const void *w_img, const fl
     cus = cached_cus;
     hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(512), lds, (hipStream_t)stream, g);
     return rac_launch_status("rac_gemm_f16x3_fwd");
+}
+
+extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha,
+                                 float *out, int N, int H, int W, int Cin, int Cin_image, int Cout, void *stream)
+{
+    RAC_CHECK_ARG(Cout == 64, "rac_conv3x3s2_fwd: built for 64 output channels (got %d)", Cout);
+    RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0 && Cin_image % 32 == 0 && Cin <= Cin_image, "rac_conv3x3s2_fwd: Cin=%d Cin_image=%d", Cin, Cin_image);
+    RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ((H / 2) * (W / 2)) % CV_TM == 0 && ((H / 2) * (W / 2)) % 4 == 0,
+                  "rac_conv3x3s2_fwd: H=%d W=%d (even, (H/2)*(W/2) a multiple of %d)", H, W, CV_TM);
+    if (N == 0)
+        return 0;
+    RAC_CHECK_ARG(xs && ws && amax && out, "rac_conv3x3s2_fwd: null pointer");
+    ConvS2Args a;
+    a.xs = reinterpret_cast<const uint4 *>(xs);
+    a.ws = reinterpret_cast<const uint4 *>(ws);
+    a.bias = bias; a.amax = amax; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.chunks_total = Cin_image / 32; a.w_alpha = w_alpha;
+    const int lds = 2 * (2048 + 512) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3s2_c64_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3s2_c64_f16x3_kernel, dim3((unsigned)(N * ((H / 2) * (W / 2) / CV_TM))), dim3(512), lds, (hipStream_t)stream, a);
+    return rac_launch_status("rac_conv3x3s2_fwd");
 }

@@ -331,15 +331,16 @@ def layer_tail_fused(tw, x1, bev_r, bev_l, partials, query_bbox, time_diff_safe,
 
 
 # ------------------------------------------------------------------------------------------- 3x3 convolution
-def pack_conv3x3_weight(weight):
-    """nn.Conv2d weight [256, Cin, 3, 3] fp32 -> (ws f16 [9, Cin/32, 256, 2, 32], w_alpha) for rac_conv3x3_fwd:
+def pack_conv3x3_weight(weight, cout=256):
+    """nn.Conv2d weight [cout, Cin, 3, 3] fp32 -> (ws f16 [9, Cin/32, cout, 2, 32], w_alpha) for rac_conv3x3_fwd (cout 256) /
+    rac_conv3x3s2_fwd (cout 64):
     hi / lo of weight * 2^s per (tap, 32-channel chunk, output channel), w_alpha = 2^-s.  (None, None) if the
     weights cannot be held."""
     import math
     w = weight.detach().float()
     co, ci, kh, kw = w.shape
     amax = float(w.abs().max())
-    if (kh, kw) != (3, 3) or co != 256 or ci % 32 != 0 or not (amax > 0.0) or amax != amax or amax == float("inf"):
+    if (kh, kw) != (3, 3) or co != cout or ci % 32 != 0 or not (amax > 0.0) or amax != amax or amax == float("inf"):
         return None, None
     s = 13 - math.frexp(amax)[1] + 1
     ws = (w * (2.0 ** s)).permute(2, 3, 1, 0).reshape(9, ci // 32, 32, co).permute(0, 1, 3, 2)      # [tap, chunk, co, 32]
@@ -351,49 +352,82 @@ def pack_conv3x3_weight(weight):
 _conv_images = {}
 
 
+class ConvImage:
+    """The padded channel-last f16 hi/lo activation image of the convolution kernels, filled in stages:
+    ``begin`` (absmax -> the activations' power-of-two scale), ``pack`` (NCHW fp32 source -> a channel range), then
+    ``conv`` (3x3 stride 1 -> [N,H,W,256] channel-last) and / or ``conv_s2`` (3x3 stride 2 over the first channels ->
+    [N,64,H/2,W/2]).  The buffer (zero border = the convolutions' padding) is allocated once per shape and reused."""
+
+    def __init__(self, N, H, W, cin, device):
+        self.N, self.H, self.W, self.cin, self.dev = N, H, W, cin, device
+        key = (N, H, W, cin, str(device))
+        xs = _conv_images.get(key)
+        if xs is None:
+            xs = _conv_images[key] = torch.zeros(N, H + 2, W + 2, cin // 32, 2, 32, device=device, dtype=torch.float16)
+        self.xs = xs
+        self.amax = torch.empty(1, device=device, dtype=torch.float32)
+
+    def begin(self, scan, floor=0.0):
+        """amax = max(floor, max |v| over the tensors in ``scan``); every source packed later must be covered by it."""
+        n = len(scan)
+        _lib.require_gpu(*scan, what="ConvImage.begin")
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in scan])
+        counts = (ctypes.c_int64 * max(n, 1))(*[t.numel() for t in scan])
+        _lib.check(_lib.lib().rac_absmax_fwd(ptrs, counts, n, float(floor), _lib.ptr(self.amax), _lib.stream_ptr()),
+                   "rac_absmax_fwd")
+        return self
+
+    def pack(self, src, c_offset):
+        _lib.require_gpu(src, what="ConvImage.pack")
+        if tuple(src.shape[0:1] + src.shape[2:]) != (self.N, self.H, self.W) or src.dtype != torch.float32:
+            raise RuntimeError("ConvImage.pack: sources must be float32 [N,C,H,W] matching the image")
+        _lib.check(_lib.lib().rac_conv_pack_fwd(_lib.ptr(src), _lib.ptr(self.amax), _lib.ptr(self.xs), self.N, int(src.shape[1]),
+                                                self.H, self.W, self.cin, int(c_offset), _lib.stream_ptr()), "rac_conv_pack_fwd")
+        return self
+
+    def conv(self, ws, w_alpha, bias=None, pixel_bias=None):
+        N, H, W = self.N, self.H, self.W
+        out = torch.empty(N, H, W, 256, device=self.dev, dtype=torch.float32)
+        if pixel_bias is not None and (tuple(pixel_bias.shape) != (H * W, 256) or not pixel_bias.is_contiguous()
+                                       or pixel_bias.dtype != torch.float32 or not pixel_bias.is_cuda):
+            raise RuntimeError("ConvImage.conv: pixel_bias must be a contiguous float32 CUDA [H*W, 256] tensor")
+        ev = _lib.timer.record("temporal_fusion_conv") if _lib.timer is not None else None
+        if ev:
+            ev[0].record()
+        _lib.check(_lib.lib().rac_conv3x3_fwd(_lib.ptr(self.xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None,
+                                              _lib.ptr(pixel_bias) if pixel_bias is not None else None, _lib.ptr(self.amax),
+                                              float(w_alpha), _lib.ptr(out), N, H, W, self.cin, 256, _lib.stream_ptr()),
+                   "rac_conv3x3_fwd")
+        if ev:
+            ev[1].record()
+        return out
+
+    def conv_s2(self, ws, w_alpha, bias, cin):
+        """3x3 / stride 2 / pad 1 convolution of the image's first ``cin`` channels -> [N, 64, H/2, W/2] fp32 (NCHW)."""
+        N, H, W = self.N, self.H, self.W
+        out = torch.empty(N, 64, H // 2, W // 2, device=self.dev, dtype=torch.float32)
+        _lib.check(_lib.lib().rac_conv3x3s2_fwd(_lib.ptr(self.xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None,
+                                                _lib.ptr(self.amax), float(w_alpha), _lib.ptr(out), N, H, W, int(cin), self.cin, 64,
+                                                _lib.stream_ptr()), "rac_conv3x3s2_fwd")
+        return out
+
+
 def conv3x3_fused(sources, ws, w_alpha, bias, bounds=None, pixel_bias=None):
     """3x3 / stride 1 / pad 1 convolution of the channel concatenation of ``sources`` (NCHW fp32 tensors with
-    equal N, H, W) -> [N, H, W, 256] fp32 channel-last.  absmax -> pack (NCHW fp32 -> padded channel-last f16
-    hi/lo image) -> implicit-GEMM kernel; the padded image buffer is allocated (zeroed) once per shape.
+    equal N, H, W) -> [N, H, W, 256] fp32 channel-last: ConvImage.begin -> pack ... -> conv in one call.
     ``bounds[i]``: a known upper bound of |sources[i]| (the source is then not scanned by the absmax pass).
     ``pixel_bias``: [H*W, 256] additive map (per pixel and output channel, shared by the N images) instead of ``bias``."""
     _lib.require_gpu(*sources, ws, what="conv3x3_fused")
     N, _, H, W = sources[0].shape
     cin = sum(int(t.shape[1]) for t in sources)
-    dev = sources[0].device
-    key = (N, H, W, cin, str(dev))
-    xs = _conv_images.get(key)
-    if xs is None:
-        xs = _conv_images[key] = torch.zeros(N, H + 2, W + 2, cin // 32, 2, 32, device=dev, dtype=torch.float16)
-    amax = torch.empty(1, device=dev, dtype=torch.float32)
     bounds = list(bounds) if bounds is not None else [None] * len(sources)
-    scan = [t for t, bnd in zip(sources, bounds) if bnd is None]
-    floor = max([0.0] + [float(bnd) for bnd in bounds if bnd is not None])
-    n = len(scan)
-    ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in scan])
-    counts = (ctypes.c_int64 * max(n, 1))(*[t.numel() for t in scan])
-    L = _lib.lib()
-    ev = _lib.timer.record("temporal_fusion_conv") if _lib.timer is not None else None
-    if ev:
-        ev[0].record()
-    _lib.check(L.rac_absmax_fwd(ptrs, counts, n, floor, _lib.ptr(amax), _lib.stream_ptr()), "rac_absmax_fwd")
+    img = ConvImage(N, H, W, cin, sources[0].device)
+    img.begin([t for t, bnd in zip(sources, bounds) if bnd is None], max([0.0] + [float(b) for b in bounds if b is not None]))
     off = 0
     for t in sources:
-        if tuple(t.shape[0:1] + t.shape[2:]) != (N, H, W) or t.dtype != torch.float32:
-            raise RuntimeError("conv3x3_fused: sources must be float32 [N,C,H,W] with equal N, H, W")
-        _lib.check(L.rac_conv_pack_fwd(_lib.ptr(t), _lib.ptr(amax), _lib.ptr(xs), N, int(t.shape[1]), H, W, cin, off,
-                                       _lib.stream_ptr()), "rac_conv_pack_fwd")
+        img.pack(t, off)
         off += int(t.shape[1])
-    out = torch.empty(N, H, W, 256, device=dev, dtype=torch.float32)
-    if pixel_bias is not None and (tuple(pixel_bias.shape) != (H * W, 256) or not pixel_bias.is_contiguous()
-                                   or pixel_bias.dtype != torch.float32 or not pixel_bias.is_cuda):
-        raise RuntimeError("conv3x3_fused: pixel_bias must be a contiguous float32 CUDA [H*W, 256] tensor")
-    _lib.check(L.rac_conv3x3_fwd(_lib.ptr(xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None,
-                                 _lib.ptr(pixel_bias) if pixel_bias is not None else None, _lib.ptr(amax),
-                                 float(w_alpha), _lib.ptr(out), N, H, W, cin, 256, _lib.stream_ptr()), "rac_conv3x3_fwd")
-    if ev:
-        ev[1].record()
-    return out
+    return img.conv(ws, w_alpha, bias, pixel_bias)
 
 
 # ------------------------------------------------------------------------------------------- temporal encoder pieces

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, gemm_f16x3, pack_gemm_weight_f16x3, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, row_gemm, row_seg, rowgemm_launch, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, gemm_f16x3, pack_gemm_weight_f16x3, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, row_gemm, row_seg, rowgemm_launch, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
                     pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
 from .msda import msda_forward
 from .msmv import msmv_forward
@@ -321,19 +321,25 @@ class RadarBEVTemporalEncoder(nn.Module):
         r = self.downsample_ratio
         x = bev_feats.flatten(0, 1)   # NCHW: an NHWC (channels_last) pipeline measured 3 % slower end to end
         down = self.downsample(x).reshape(B, T, self.hidden_dims, H // r, W // r)
+        return x, self.hidden_from_down(down, H, W)
+
+    def hidden_from_down(self, down, H, W):
+        """ConvGRU -> upsample on the downsampled maps [B,T,hidden,H/r,W/r] -> [B*T,hidden,H,W]."""
+        B, T = down.shape[:2]
+        r = self.downsample_ratio
         gru = self.convGRU(down)
         Tv = min(4, T)
-        if not (x.is_cuda and x.dtype == torch.float32 and r == 2 and Tv < T):
-            return x, self.upsample(gru.flatten(0, 1))
+        if not (down.is_cuda and down.dtype == torch.float32 and r == 2 and Tv < T):
+            return self.upsample(gru.flatten(0, 1))
         # ConvGRU leaves the frames t >= 4 at zero (:674-693): their upsample is zero and the 3x3 convolution of an
         # all-zero map is exactly its bias, so only the first frames go through the resize (one HIP launch instead
         # of torch's generic kernel) and the convolution.
         conv = self.upsample[1]
         hv = conv(upsample2x_fused(gru[:, :Tv].reshape(B * Tv, self.hidden_dims, H // r, W // r)))
-        hid = torch.empty(B, T, self.hidden_dims, H, W, device=x.device, dtype=x.dtype)
+        hid = torch.empty(B, T, self.hidden_dims, H, W, device=down.device, dtype=down.dtype)
         hid[:, :Tv] = hv.view(B, Tv, self.hidden_dims, H, W)
         hid[:, Tv:] = (conv.bias if conv.bias is not None else hv.new_zeros(self.hidden_dims)).view(1, 1, -1, 1, 1)
-        return x, hid.flatten(0, 1)
+        return hid.flatten(0, 1)
 
     def forward(self, bev_feats):
         B, T, C, H, W = bev_feats.shape
@@ -345,6 +351,14 @@ class RadarBEVTemporalEncoder(nn.Module):
     # f16 matrix cores, hi/lo-split operands, fp32-convolution accuracy); no concatenation, no layout transposes,
     # output already channel-last for value_proj.
     fused_conv = True
+
+    def downsample_pack(self):
+        """Packed weights of the stride-2 downsample convolution for rac_conv3x3s2_fwd ({} if not 3x3 / 64 channels)."""
+        d = self.downsample
+        if self.hidden_dims != 64 or d.kernel_size != (3, 3) or d.stride != (2, 2) or d.padding != (1, 1):
+            return {}
+        ws, alpha = pack_conv3x3_weight(d.weight, cout=64)
+        return dict(down_ws=ws, down_alpha=alpha) if ws is not None else {}
 
     def hidden_bound(self):
         """Upper bound of |hidden_stream(.)[1]| from the weights of the last convolution (inputs bounded by 1)."""
@@ -362,12 +376,26 @@ class RadarBEVTemporalEncoder(nn.Module):
         """-> [B*T, H, W, C] (channel-last).  ``packed``: dict(ws, alpha = pack_conv3x3_weight(.), bound = hidden_bound(),
         optional pixel_bias [H*W, C] replacing the convolution's bias); ``hidden``: hidden_stream(bev_feats) if the
         caller already ran it (on a side stream)."""
-        x, hid = hidden if hidden is not None else self.hidden_stream(bev_feats)
         # |ConvGRU state| <= 1 (convex combinations of tanh values, zero start), bilinear resizing keeps that, so
-        # |hid| <= max_row ||W_up||_1 + max|b_up|: known from the weights, no need to scan the tensor
+        # |hid| <= max_row ||W_up||_1 + max|b_up|: known from the weights, only the input maps are scanned for the scale
+        B, T, C, H, W = bev_feats.shape
         pb = packed.get("pixel_bias")
-        return conv3x3_fused([x.contiguous(), hid.contiguous()], packed["ws"], packed["alpha"],
-                             None if pb is not None else self.temporal_fusion.bias, bounds=[None, packed["bound"]], pixel_bias=pb)
+        img = ConvImage(B * T, H, W, C + self.hidden_dims, bev_feats.device)
+        if hidden is not None:
+            x, hid = hidden
+            img.begin([x.contiguous()], packed["bound"]).pack(x.contiguous(), 0)
+        else:
+            x = bev_feats.flatten(0, 1).contiguous()
+            img.begin([x], packed["bound"]).pack(x, 0)
+            if packed.get("down_ws") is not None and self.downsample_ratio == 2 and ((H // 2) * (W // 2)) % 256 == 0:
+                # downsample (3x3, stride 2) on the image that is being built for the fusion convolution anyway
+                down = img.conv_s2(packed["down_ws"], packed["down_alpha"], self.downsample.bias, C)
+                down = down.view(B, T, self.hidden_dims, H // 2, W // 2)
+            else:
+                down = self.downsample(x).reshape(B, T, self.hidden_dims, H // self.downsample_ratio, W // self.downsample_ratio)
+            hid = self.hidden_from_down(down, H, W)
+        img.pack(hid.contiguous(), C)
+        return img.conv(packed["ws"], packed["alpha"], None if pb is not None else self.temporal_fusion.bias, pb)
 
 
 class BEVSelfAttention(nn.Module):
@@ -505,7 +533,7 @@ class BEVSampling(nn.Module):
             return {}
         pos = self.positional_encoding.grid(H, W).detach().double().reshape(-1, H * W)            # [C, HW]
         pixel_bias = (pos.t() @ wv.t() + (wv @ bc + bv)).float().contiguous()                          # [HW, C]
-        return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), pixel_bias=pixel_bias)
+        return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), pixel_bias=pixel_bias, **te.downsample_pack())
 
     def keypoints(self, query_ray, query_feat, time_diff, d_region):
         """-> loc [B,Q,heads,T,P,2] in [0,1], weights [B,Q,heads,T,1,P] (:490-529)."""
@@ -808,7 +836,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         conv_pack = None
         if radar_bev_feats.is_cuda and self.fused and te.fused_conv:
             Hr, Wr = radar_bev_feats.shape[-2:]
-            conv_params = [te.temporal_fusion.weight, up.weight] + [m.bias for m in (te.temporal_fusion, up) if m.bias is not None]
+            conv_params = [te.temporal_fusion.weight, up.weight, te.downsample.weight] + \
+                [m.bias for m in (te.temporal_fusion, up) if m.bias is not None]
             if self.compose_radar_value:
                 pe_, vp = rbs.positional_encoding, rbs.attention.value_proj
                 conv_pack = self._cached(f"conv_value_pack_{Hr}x{Wr}", conv_params + [vp.weight, vp.bias, pe_.row_embed.weight,
@@ -817,7 +846,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             if not conv_pack:
                 def plain_pack():
                     ws, alpha = pack_conv3x3_weight(te.temporal_fusion.weight)
-                    return dict(ws=ws, alpha=alpha, bound=te.hidden_bound())
+                    return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), **te.downsample_pack())
                 conv_pack = self._cached("conv_pack", conv_params, plain_pack)
         lbs = self.sampling_lss_bev
         if lss_bev_feats.is_cuda and self.fused:

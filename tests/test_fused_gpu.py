@@ -315,7 +315,7 @@ def test_temporal_encoder_fused_pieces():
         ref = enc(bev)                                                     # CPU: the reference decomposition
         eg = enc.to(DEV)
         ws, alpha = pack_conv3x3_weight(eg.temporal_fusion.weight)
-        got = eg.forward_channel_last(bev.to(DEV), dict(ws=ws, alpha=alpha, bound=eg.hidden_bound()))
+        got = eg.forward_channel_last(bev.to(DEV), dict(ws=ws, alpha=alpha, bound=eg.hidden_bound(), **eg.downsample_pack()))
     assert (got.permute(0, 3, 1, 2).cpu() - ref[0]).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
 
 
@@ -450,3 +450,25 @@ def test_decode_kernel_matches_torch_decode(Q, C, K):
     assert d.min(1).values.max().item() < 1e-4 and d.min(0).values.max().item() < 1e-4
     if K > n:
         assert bool((got[n:, 9] == -1).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 320), (8, 128, 128, 320)])
+def test_conv3x3_stride2_kernel(shape):
+    """rac_conv3x3s2_fwd (the temporal encoder's downsample convolution on the image's first 256 channels) vs torch."""
+    from racformer_amd.fused import ConvImage, pack_conv3x3_weight
+    N, H, W, C = shape
+    torch.manual_seed(H)
+    conv = torch.nn.Conv2d(256, 64, 3, stride=2, padding=1)
+    x, rest = torch.randn(N, 256, H, W) * 2.0, torch.randn(N, C - 256, H, W)
+    img = ConvImage(N, H, W, C, torch.device(DEV))
+    xg, rg = x.to(DEV), rest.to(DEV)
+    img.begin([xg, rg]).pack(xg, 0).pack(rg, 256)
+    ws, alpha = pack_conv3x3_weight(conv.weight.to(DEV), cout=64)
+    got = img.conv_s2(ws, alpha, conv.bias.detach().to(DEV), 256)
+    assert tuple(got.shape) == (N, 64, H // 2, W // 2)
+    with torch.no_grad():
+        if N * H * W <= 4096:
+            want, tol = conv.double()(x.double()), 4e-6
+        else:
+            want, tol = conv.to(DEV)(xg).double().cpu(), 2e-5
+    assert (got.double().cpu() - want).abs().max().item() <= tol * want.abs().max().item()

@@ -279,7 +279,7 @@ int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream);
 
 /* The downsample convolution of RadarBEVTemporalEncoder (3x3, stride 2, pad 1, Cin -> 64; models/racformer_transformer.py:632,646)
  * on the activation image of rac_conv_pack_fwd (its first Cin channels; the image holds Cin_image >= Cin channels) with the
- * arithmetic of rac_conv3x3_fwd.  ws = f16 [9 taps][Cin/32][64][2][32];  out [N,64,H/2,W/2] f32 (NCHW);  (H/2)*(W/2) % 256 == 0. */
+ * arithmetic of rac_conv3x3_fwd.  ws = f16 [9 taps][Cin/32][64][2][32];  out [N,64,H/2,W/2] f32 (NCHW);  (H/2)*(W/2) % 128 == 0. */
 int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out, int N,
                       int H, int W, int Cin, int Cin_image, int Cout, void *stream);
 

@@ -252,28 +252,29 @@ struct ConvS2Args {
     float w_alpha;
 };
 
-__global__ __launch_bounds__(512, 1) void conv3x3s2_c64_f16x3_kernel(const ConvS2Args a)
+#define S2_TM 128 /* output pixels per workgroup: 256 workgroups of 4 waves for the 8 x 64 x 64 maps */
+__global__ __launch_bounds__(256, 2) void conv3x3s2_c64_f16x3_kernel(const ConvS2Args a)
 {
     extern __shared__ uint4 lds4[];
-    constexpr int STAGE = 2048 + 512;   // uint4 per LDS stage: A 256 rows, B 64 rows
+    constexpr int STAGE = 1024 + 512;   // uint4 per LDS stage: A 128 rows, B 64 rows
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int H = a.H, W = a.W, Wp = W + 2, OH = H >> 1, OW = W >> 1, chunks = a.chunks;
-    const int tiles_per_img = (OH * OW) / CV_TM;
+    const int tiles_per_img = (OH * OW) / S2_TM;
     const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
     const int KS = 9 * chunks;
     const size_t pix_stride = (size_t)a.chunks_total * 8;
     auto row_base = [&](int j) -> size_t {
-        const int r = (tid >> 3) + 64 * j;
-        const int gp = tile * CV_TM + r, oh = gp / OW, ow = gp - oh * OW;
+        const int r = (tid >> 3) + 32 * j;
+        const int gp = tile * S2_TM + r, oh = gp / OW, ow = gp - oh * OW;
         return (((size_t)n * (H + 2) + 2 * oh) * Wp + 2 * ow) * pix_stride + (tid & 7);
     };
     auto row_slot = [&](int j) -> int {
-        const int r = (tid >> 3) + 64 * j;
+        const int r = (tid >> 3) + 32 * j;
         return r * 8 + ((tid & 7) ^ ((r >> 1) & 7));
     };
     const size_t a_base0 = row_base(0), a_base1 = row_base(1), a_base2 = row_base(2), a_base3 = row_base(3);
     const int st0 = row_slot(0), st1 = row_slot(1), st2 = row_slot(2), st3 = row_slot(3);
-    uint4 ra0, ra1, ra2, ra3, rb0;
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1;
 #define S2_GLOAD(ks_)                                                                          \
     do {                                                                                       \
         const int tap_ = (ks_) / chunks, chunk_ = (ks_) - tap_ * chunks;                       \
@@ -281,13 +282,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c64_f16x3_kernel(const ConvS
         const size_t off_ = ((size_t)dy_ * Wp + dx_) * pix_stride + (size_t)chunk_ * 8;        \
         ra0 = a.xs[a_base0 + off_]; ra1 = a.xs[a_base1 + off_];                                \
         ra2 = a.xs[a_base2 + off_]; ra3 = a.xs[a_base3 + off_];                                \
-        rb0 = a.ws[(size_t)(ks_) * 512 + tid];                                                 \
+        rb0 = a.ws[(size_t)(ks_) * 512 + tid]; rb1 = a.ws[(size_t)(ks_) * 512 + 256 + tid];          \
     } while (0)
 #define S2_LSTORE(buf_)                                                                        \
     do {                                                                                       \
-        uint4 *A_ = lds4 + (buf_) * STAGE, *B_ = A_ + 2048;                                    \
+        uint4 *A_ = lds4 + (buf_) * STAGE, *B_ = A_ + 1024;                                    \
         A_[st0] = ra0; A_[st1] = ra1; A_[st2] = ra2; A_[st3] = ra3;                            \
-        B_[st0] = rb0;                                                                         \
+        B_[st0] = rb0; B_[st1] = rb1;                                                          \
     } while (0)
 
     cv_f4 acc[2][4];
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c64_f16x3_kernel(const ConvS
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
         const int row = 16 * nn + li, f = (row >> 1) & 7;
-        bidx_h[nn] = 2048 + row * 8 + (lk ^ f);
-        bidx_l[nn] = 2048 + row * 8 + ((4 + lk) ^ f);
+        bidx_h[nn] = 1024 + row * 8 + (lk ^ f);
+        bidx_l[nn] = 1024 + row * 8 + ((4 + lk) ^ f);
     }
     const int arow0 = 32 * wave + li;
 
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_c64_f16x3_kernel(const ConvS
     }
     // epilogue: NCHW store -- for a channel (column li) the lane's 4 accumulator rows are 4 consecutive output pixels
     const float unscale = a.w_alpha / cv_act_scale(*a.amax);
-    float *obase = a.out + (size_t)n * 64 * OH * OW + (size_t)tile * CV_TM;
+    float *obase = a.out + (size_t)n * 64 * OH * OW + (size_t)tile * S2_TM;
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
         const int co = 16 * nn + li;
@@ -568,8 +569,8 @@ extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bi
 {
     RAC_CHECK_ARG(Cout == 64, "rac_conv3x3s2_fwd: built for 64 output channels (got %d)", Cout);
     RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0 && Cin_image % 32 == 0 && Cin <= Cin_image, "rac_conv3x3s2_fwd: Cin=%d Cin_image=%d", Cin, Cin_image);
-    RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ((H / 2) * (W / 2)) % CV_TM == 0 && ((H / 2) * (W / 2)) % 4 == 0,
-                  "rac_conv3x3s2_fwd: H=%d W=%d (even, (H/2)*(W/2) a multiple of %d)", H, W, CV_TM);
+    RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ((H / 2) * (W / 2)) % S2_TM == 0,
+                  "rac_conv3x3s2_fwd: H=%d W=%d (even, (H/2)*(W/2) a multiple of %d)", H, W, S2_TM);
     if (N == 0)
         return 0;
     RAC_CHECK_ARG(xs && ws && amax && out, "rac_conv3x3s2_fwd: null pointer");
@@ -578,12 +579,12 @@ extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bi
     a.ws = reinterpret_cast<const uint4 *>(ws);
     a.bias = bias; a.amax = amax; a.out = out;
     a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.chunks_total = Cin_image / 32; a.w_alpha = w_alpha;
-    const int lds = 2 * (2048 + 512) * 16;
+    const int lds = 2 * (1024 + 512) * 16;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3s2_c64_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3s2_c64_f16x3_kernel, dim3((unsigned)(N * ((H / 2) * (W / 2) / CV_TM))), dim3(512), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3s2_c64_f16x3_kernel, dim3((unsigned)(N * ((H / 2) * (W / 2) / S2_TM))), dim3(256), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_conv3x3s2_fwd");
 }

@@ -387,7 +387,7 @@ class RadarBEVTemporalEncoder(nn.Module):
         else:
             x = bev_feats.flatten(0, 1).contiguous()
             img.begin([x], packed["bound"]).pack(x, 0)
-            if packed.get("down_ws") is not None and self.downsample_ratio == 2 and ((H // 2) * (W // 2)) % 256 == 0:
+            if packed.get("down_ws") is not None and self.downsample_ratio == 2 and ((H // 2) * (W // 2)) % 128 == 0:
                 # downsample (3x3, stride 2) on the image that is being built for the fusion convolution anyway
                 down = img.conv_s2(packed["down_ws"], packed["down_alpha"], self.downsample.bias, C)
                 down = down.view(B, T, self.hidden_dims, H // 2, W // 2)

@@ -252,11 +252,16 @@ struct ConvS2Args {
     float w_alpha;
 };
 
-#define S2_TM 128 /* output pixels per workgroup: 256 workgroups of 4 waves for the 8 x 64 x 64 maps */
-__global__ __launch_bounds__(256, 2) void conv3x3s2_c64_f16x3_kernel(const ConvS2Args a)
+#ifndef S2_TM
+#define S2_TM 128 /* output pixels per workgroup: 256 workgroups of 4 waves for the 8 x 64 x 64 maps (64: 79 us, 128: 77 us, 256: 86 us) */
+#endif
+#define S2_THREADS (2 * S2_TM)
+#define S2_RSTEP (S2_THREADS / 8) /* tile rows staged per pass */
+#define S2_NB (64 / S2_RSTEP)     /* passes for the 64 weight rows */
+__global__ __launch_bounds__(S2_THREADS, 2) void conv3x3s2_c64_f16x3_kernel(const ConvS2Args a)
 {
     extern __shared__ uint4 lds4[];
-    constexpr int STAGE = 1024 + 512;   // uint4 per LDS stage: A 128 rows, B 64 rows
+    constexpr int STAGE = S2_TM * 8 + 512;   // uint4 per LDS stage: A S2_TM rows, B 64 rows
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int H = a.H, W = a.W, Wp = W + 2, OH = H >> 1, OW = W >> 1, chunks = a.chunks;
     const int tiles_per_img = (OH * OW) / S2_TM;
@@ -264,17 +269,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_f16x3_kernel(const ConvS
     const int KS = 9 * chunks;
     const size_t pix_stride = (size_t)a.chunks_total * 8;
     auto row_base = [&](int j) -> size_t {
-        const int r = (tid >> 3) + 32 * j;
+        const int r = (tid >> 3) + S2_RSTEP * j;
         const int gp = tile * S2_TM + r, oh = gp / OW, ow = gp - oh * OW;
         return (((size_t)n * (H + 2) + 2 * oh) * Wp + 2 * ow) * pix_stride + (tid & 7);
     };
     auto row_slot = [&](int j) -> int {
-        const int r = (tid >> 3) + 32 * j;
+        const int r = (tid >> 3) + S2_RSTEP * j;
         return r * 8 + ((tid & 7) ^ ((r >> 1) & 7));
     };
     const size_t a_base0 = row_base(0), a_base1 = row_base(1), a_base2 = row_base(2), a_base3 = row_base(3);
     const int st0 = row_slot(0), st1 = row_slot(1), st2 = row_slot(2), st3 = row_slot(3);
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1;
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define S2_GLOAD(ks_)                                                                          \
     do {                                                                                       \
         const int tap_ = (ks_) / chunks, chunk_ = (ks_) - tap_ * chunks;                       \
@@ -282,13 +287,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_f16x3_kernel(const ConvS
         const size_t off_ = ((size_t)dy_ * Wp + dx_) * pix_stride + (size_t)chunk_ * 8;        \
         ra0 = a.xs[a_base0 + off_]; ra1 = a.xs[a_base1 + off_];                                \
         ra2 = a.xs[a_base2 + off_]; ra3 = a.xs[a_base3 + off_];                                \
-        rb0 = a.ws[(size_t)(ks_) * 512 + tid]; rb1 = a.ws[(size_t)(ks_) * 512 + 256 + tid];          \
+        rb0 = a.ws[(size_t)(ks_) * 512 + tid]; rb1 = a.ws[(size_t)(ks_) * 512 + S2_THREADS + tid];   \
+        if (S2_NB > 2) {                                                                       \
+            rb2 = a.ws[(size_t)(ks_) * 512 + 2 * S2_THREADS + tid];                            \
+            rb3 = a.ws[(size_t)(ks_) * 512 + 3 * S2_THREADS + tid];                            \
+        }                                                                                      \
     } while (0)
 #define S2_LSTORE(buf_)                                                                        \
     do {                                                                                       \
-        uint4 *A_ = lds4 + (buf_) * STAGE, *B_ = A_ + 1024;                                    \
+        uint4 *A_ = lds4 + (buf_) * STAGE, *B_ = A_ + S2_TM * 8;                               \
         A_[st0] = ra0; A_[st1] = ra1; A_[st2] = ra2; A_[st3] = ra3;                            \
         B_[st0] = rb0; B_[st1] = rb1;                                                          \
+        if (S2_NB > 2) {                                                                       \
+            B_[st2] = rb2; B_[st3] = rb3;                                                      \
+        }                                                                                      \
     } while (0)
 
     cv_f4 acc[2][4];
@@ -301,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_c64_f16x3_kernel(const ConvS
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
         const int row = 16 * nn + li, f = (row >> 1) & 7;
-        bidx_h[nn] = 1024 + row * 8 + (lk ^ f);
-        bidx_l[nn] = 1024 + row * 8 + ((4 + lk) ^ f);
+        bidx_h[nn] = S2_TM * 8 + row * 8 + (lk ^ f);
+        bidx_l[nn] = S2_TM * 8 + row * 8 + ((4 + lk) ^ f);
     }
     const int arow0 = 32 * wave + li;
 
@@ -579,12 +591,12 @@ extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bi
     a.ws = reinterpret_cast<const uint4 *>(ws);
     a.bias = bias; a.amax = amax; a.out = out;
     a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.chunks_total = Cin_image / 32; a.w_alpha = w_alpha;
-    const int lds = 2 * (1024 + 512) * 16;
+    const int lds = 2 * (S2_TM * 8 + 512) * 16;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3s2_c64_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3s2_c64_f16x3_kernel, dim3((unsigned)(N * ((H / 2) * (W / 2) / S2_TM))), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3s2_c64_f16x3_kernel, dim3((unsigned)(N * ((H / 2) * (W / 2) / S2_TM))), dim3(S2_THREADS), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_conv3x3s2_fwd");
 }

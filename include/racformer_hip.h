@@ -240,11 +240,12 @@ int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const flo
 /* Element-wise pieces of RadarBEVTemporalEncoder (models/racformer_transformer.py:618-720).
  *   rac_gru_gate_fwd   ConvGRUCell update after the gates convolution (:705-720): gates [B,3C,H,W] (z | r | cand),
  *                      h_prev [B,C,H,W] (batch stride h_prev_bstride floats) -> h_out (batch stride h_out_bstride):
- *                      h = (1 - sigmoid(z)) * h_prev + sigmoid(z) * tanh(cand + sigmoid(r) * h_prev)
+ *                      h = (1 - sigmoid(z)) * h_prev + sigmoid(z) * tanh(cand + sigmoid(r) * h_prev);
+ *                      bias_map (optional [3C,H,W]) is added to the gates first; h_out2 (optional) receives h as well
  *   rac_upsample2x_fwd nn.Upsample(scale_factor=2, bilinear, align_corners=True) (:633-636) on `planes` = N*C maps
  *                      [h,w] -> [2h,2w] */
 int rac_gru_gate_fwd(const float *gates, const float *h_prev, int64_t h_prev_bstride, float *h_out, int64_t h_out_bstride,
-                     int B, int C, int HW, void *stream);
+                     const float *bias_map, float *h_out2, int64_t h_out2_bstride, int B, int C, int HW, void *stream);
 int rac_upsample2x_fwd(const float *src, float *dst, int64_t planes, int h, int w, void *stream);
 
 /* The small dense layers of a decoder layer with their surrounding row-wise work in one launch
@@ -279,9 +280,10 @@ int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream);
 
 /* The downsample convolution of RadarBEVTemporalEncoder (3x3, stride 2, pad 1, Cin -> 64; models/racformer_transformer.py:632,646)
  * on the activation image of rac_conv_pack_fwd (its first Cin channels; the image holds Cin_image >= Cin channels) with the
- * arithmetic of rac_conv3x3_fwd.  ws = f16 [9 taps][Cin/32][64][2][32];  out [N,64,H/2,W/2] f32 (NCHW);  (H/2)*(W/2) % 128 == 0. */
-int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out, int N,
-                      int H, int W, int Cin, int Cin_image, int Cout, void *stream);
+ * arithmetic of rac_conv3x3_fwd.  ws = f16 [9 taps][Cin/32][64][2][32];  out: channels 0..63 of an NCHW f32 buffer
+ * [N, out_channels_total, H/2, W/2] (64 for a plain output);  (H/2)*(W/2) % 128 == 0. */
+int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
+                      int out_channels_total, int N, int H, int W, int Cin, int Cin_image, int Cout, void *stream);
 
 /* Split-precision GEMM on the f16 matrix cores (3 products, fp32 accumulate, fp32-GEMM accuracy; hand-written, same inner
  * loop as rac_conv3x3_fwd):  out[M][N] = alpha * (A @ W^T) + bias.  Replaces the nn.Linear `parameter_generator` of

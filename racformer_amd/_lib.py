@@ -38,12 +38,12 @@ SIGNATURES = {
     "rac_decode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _i, _vp]),
     "rac_gemm_f16x3_fwd": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "rac_rowgemm_fwd": (_i, [_vp, _i, _i, _vp]),
-    "rac_gru_gate_fwd": (_i, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
+    "rac_gru_gate_fwd": (_i, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
     "rac_upsample2x_fwd": (_i, [_vp, _vp, ctypes.c_int64, _i, _i, _vp]),
     "rac_absmax_fwd": (_i, [_vp, _vp, _i, _f, _vp, _vp]),
     "rac_conv_pack_fwd": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_vp]),
     "rac_conv3x3_fwd": (_i, [_vp] * 5 + [_f, _vp] + [_i] * 5 + [_vp]),
-    "rac_conv3x3s2_fwd": (_i, [_vp] * 4 + [_f, _vp] + [_i] * 6 + [_vp]),
+    "rac_conv3x3s2_fwd": (_i, [_vp] * 4 + [_f, _vp] + [_i] * 7 + [_vp]),
     "rac_bev_sampling_fwd": (_i, [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
 }
 

@@ -247,8 +247,8 @@ struct ConvS2Args {
     const uint4 *ws;      // [9][chunks][64][hi 32 | lo 32]
     const float *bias;
     const float *amax;
-    float *out;           // [N][64][OH][OW]
-    int N, H, W, chunks, chunks_total;
+    float *out;           // [N][out_ctotal][OH][OW], channels 0..63 written
+    int N, H, W, chunks, chunks_total, out_ctotal;
     float w_alpha;
 };
 
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv3x3s2_c64_f16x3_kernel(cons
     }
     // epilogue: NCHW store -- for a channel (column li) the lane's 4 accumulator rows are 4 consecutive output pixels
     const float unscale = a.w_alpha / cv_act_scale(*a.amax);
-    float *obase = a.out + (size_t)n * 64 * OH * OW + (size_t)tile * S2_TM;
+    float *obase = a.out + (size_t)n * a.out_ctotal * OH * OW + (size_t)tile * S2_TM;
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
         const int co = 16 * nn + li;
@@ -577,8 +577,10 @@ extern "C" int rac_gemm_f16x3_fwd(const void *a_img, const void *w_img, const fl
 }
 
 extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha,
-                                 float *out, int N, int H, int W, int Cin, int Cin_image, int Cout, void *stream)
+                                 float *out, int out_channels_total, int N, int H, int W, int Cin, int Cin_image, int Cout,
+                                 void *stream)
 {
+    RAC_CHECK_ARG(out_channels_total >= 64, "rac_conv3x3s2_fwd: out_channels_total=%d", out_channels_total);
     RAC_CHECK_ARG(Cout == 64, "rac_conv3x3s2_fwd: built for 64 output channels (got %d)", Cout);
     RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0 && Cin_image % 32 == 0 && Cin <= Cin_image, "rac_conv3x3s2_fwd: Cin=%d Cin_image=%d", Cin, Cin_image);
     RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ((H / 2) * (W / 2)) % S2_TM == 0,
@@ -590,7 +592,7 @@ extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bi
     a.xs = reinterpret_cast<const uint4 *>(xs);
     a.ws = reinterpret_cast<const uint4 *>(ws);
     a.bias = bias; a.amax = amax; a.out = out;
-    a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.chunks_total = Cin_image / 32; a.w_alpha = w_alpha;
+    a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.chunks_total = Cin_image / 32; a.out_ctotal = out_channels_total; a.w_alpha = w_alpha;
     const int lds = 2 * (S2_TM * 8 + 512) * 16;
     static bool attr_set = false;
     if (!attr_set) {

@@ -7,15 +7,25 @@
 //   z = sigmoid(g[0:C]), r = sigmoid(g[C:2C]), cand = tanh(g[2C:3C] + r * h_prev), h = (1 - z) * h_prev + z * cand
 // gates [B][3C][HW], h_prev [B][C][HW] (batch stride hp_bstride), h_out [B][C][HW] (batch stride ho_bstride: the step's
 // slot of the [B,T,C,H,W] output, which is also the next step's h_prev).
+// Optional: bias_map [3C][HW] added to the gates first (the gates convolution then runs without bias; the map also carries
+// the composed matching-layer term, see ConvGRU.fused_pack), h_out2 = a second destination of h (the hidden half of the
+// next step's convolution input), so that no concatenation / copy is launched per step.
 __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__ gates, const float *__restrict__ h_prev,
-                                                       long hp_bstride, float *__restrict__ h_out, long ho_bstride, int B,
-                                                       long chw)
+                                                       long hp_bstride, float *__restrict__ h_out, long ho_bstride,
+                                                       const float *__restrict__ bias_map, float *__restrict__ h_out2,
+                                                       long ho2_bstride, int B, long chw)
 {
     const long n4 = (long)B * (chw >> 2);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const long b = i / (chw >> 2), e = (i - b * (chw >> 2)) * 4;
         const float *g = gates + b * 3 * chw + e;
-        const rac_f4 zg = rac_ld4(g), rg = rac_ld4(g + chw), cg = rac_ld4(g + 2 * chw);
+        rac_f4 zg = rac_ld4(g), rg = rac_ld4(g + chw), cg = rac_ld4(g + 2 * chw);
+        if (bias_map) {
+            const rac_f4 bz = rac_ld4(bias_map + e), br = rac_ld4(bias_map + chw + e), bc = rac_ld4(bias_map + 2 * chw + e);
+            zg.x += bz.x; zg.y += bz.y; zg.z += bz.z; zg.w += bz.w;
+            rg.x += br.x; rg.y += br.y; rg.z += br.z; rg.w += br.w;
+            cg.x += bc.x; cg.y += bc.y; cg.z += bc.z; cg.w += bc.w;
+        }
         const rac_f4 hp = rac_ld4(h_prev + b * hp_bstride + e);
         rac_f4 o;
 #define GRU1(c)                                                   \
@@ -28,6 +38,8 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__
         GRU1(x) GRU1(y) GRU1(z) GRU1(w)
 #undef GRU1
         *reinterpret_cast<rac_f4 *>(h_out + b * ho_bstride + e) = o;
+        if (h_out2)
+            *reinterpret_cast<rac_f4 *>(h_out2 + b * ho2_bstride + e) = o;
     }
 }
 
@@ -63,10 +75,11 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float *__restrict
 }
 
 extern "C" int rac_gru_gate_fwd(const float *gates, const float *h_prev, int64_t h_prev_bstride, float *h_out,
-                                int64_t h_out_bstride, int B, int C, int HW, void *stream)
+                                int64_t h_out_bstride, const float *bias_map, float *h_out2, int64_t h_out2_bstride, int B,
+                                int C, int HW, void *stream)
 {
     const long chw = (long)C * HW;
-    RAC_CHECK_ARG(B >= 0 && C > 0 && HW > 0 && chw % 4 == 0 && h_prev_bstride % 4 == 0 && h_out_bstride % 4 == 0,
+    RAC_CHECK_ARG(B >= 0 && C > 0 && HW > 0 && chw % 4 == 0 && h_prev_bstride % 4 == 0 && h_out_bstride % 4 == 0 && h_out2_bstride % 4 == 0,
                   "rac_gru_gate_fwd: C*H*W=%ld and the batch strides must be multiples of 4", chw);
     if (B == 0)
         return 0;
@@ -74,7 +87,7 @@ extern "C" int rac_gru_gate_fwd(const float *gates, const float *h_prev, int64_t
     long blocks = ((long)B * (chw / 4) + 255) / 256;
     blocks = blocks > 4096 ? 4096 : blocks;
     hipLaunchKernelGGL(gru_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gates, h_prev,
-                       (long)h_prev_bstride, h_out, (long)h_out_bstride, B, chw);
+                       (long)h_prev_bstride, h_out, (long)h_out_bstride, bias_map, h_out2, (long)h_out2_bstride, B, chw);
     return rac_launch_status("rac_gru_gate_fwd");
 }
 

@@ -402,13 +402,17 @@ class ConvImage:
             ev[1].record()
         return out
 
-    def conv_s2(self, ws, w_alpha, bias, cin):
-        """3x3 / stride 2 / pad 1 convolution of the image's first ``cin`` channels -> [N, 64, H/2, W/2] fp32 (NCHW)."""
+    def conv_s2(self, ws, w_alpha, bias, cin, out=None):
+        """3x3 / stride 2 / pad 1 convolution of the image's first ``cin`` channels -> [N, 64, H/2, W/2] fp32 (NCHW), or
+        into channels 0..63 of a given contiguous ``out`` [N, Ctot, H/2, W/2]."""
         N, H, W = self.N, self.H, self.W
-        out = torch.empty(N, 64, H // 2, W // 2, device=self.dev, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(N, 64, H // 2, W // 2, device=self.dev, dtype=torch.float32)
+        elif not out.is_contiguous() or tuple(out.shape[0:1] + out.shape[2:]) != (N, H // 2, W // 2) or out.shape[1] < 64:
+            raise RuntimeError("ConvImage.conv_s2: out must be a contiguous [N, >=64, H/2, W/2] tensor")
         _lib.check(_lib.lib().rac_conv3x3s2_fwd(_lib.ptr(self.xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None,
-                                                _lib.ptr(self.amax), float(w_alpha), _lib.ptr(out), N, H, W, int(cin), self.cin, 64,
-                                                _lib.stream_ptr()), "rac_conv3x3s2_fwd")
+                                                _lib.ptr(self.amax), float(w_alpha), _lib.ptr(out), int(out.shape[1]), N, H, W,
+                                                int(cin), self.cin, 64, _lib.stream_ptr()), "rac_conv3x3s2_fwd")
         return out
 
 
@@ -431,17 +435,23 @@ def conv3x3_fused(sources, ws, w_alpha, bias, bounds=None, pixel_bias=None):
 
 
 # ------------------------------------------------------------------------------------------- temporal encoder pieces
-def gru_gate_fused(gates, h_prev, h_out):
-    """ConvGRUCell's element-wise update, one launch: gates [B,3C,H,W] contiguous; h_prev / h_out [B,C,H,W] views whose
-    per-batch blocks are contiguous (e.g. the [:, t] slot of a [B,T,C,H,W] tensor).  Writes h_out."""
+def gru_gate_fused(gates, h_prev, h_out, bias_map=None, h_out2=None):
+    """ConvGRUCell's element-wise update, one launch: gates [B,3C,H,W] contiguous; h_prev / h_out (/ h_out2) [B,C,H,W]
+    views whose per-batch blocks are contiguous (e.g. the [:, t] slot of a [B,T,C,H,W] tensor).  ``bias_map`` [3C,H,W]
+    is added to the gates first.  Writes h_out (and h_out2)."""
     B, C3, H, W = gates.shape
     C = C3 // 3
-    for t in (h_prev, h_out):
+    if bias_map is not None and (tuple(bias_map.shape) != (C3, H, W) or not bias_map.is_contiguous() or not bias_map.is_cuda):
+        raise RuntimeError("gru_gate_fused: bias_map must be a contiguous CUDA [3C,H,W] tensor")
+    for t in (h_prev, h_out) + ((h_out2,) if h_out2 is not None else ()):
         if not t.is_cuda or tuple(t.shape) != (B, C, H, W) or t[0].is_contiguous() is False or t.dtype != torch.float32:
             raise RuntimeError("gru_gate_fused: h_prev / h_out must be float32 CUDA [B,C,H,W] views with contiguous batches")
     _lib.require_gpu(gates, what="gru_gate_fused")
-    rc = _lib.lib().rac_gru_gate_fwd(_lib.ptr(gates), _lib.ptr(h_prev), h_prev.stride(0) if B > 1 else C * H * W, _lib.ptr(h_out),
-                                     h_out.stride(0) if B > 1 else C * H * W, B, C, H * W, _lib.stream_ptr())
+    bs = lambda t: t.stride(0) if B > 1 else C * H * W   # noqa: E731
+    rc = _lib.lib().rac_gru_gate_fwd(_lib.ptr(gates), _lib.ptr(h_prev), bs(h_prev), _lib.ptr(h_out), bs(h_out),
+                                     _lib.ptr(bias_map) if bias_map is not None else None,
+                                     _lib.ptr(h_out2) if h_out2 is not None else None, bs(h_out2) if h_out2 is not None else 0,
+                                     B, C, H * W, _lib.stream_ptr())
     _lib.check(rc, "rac_gru_gate_fwd")
     return h_out
 

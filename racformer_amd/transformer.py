@@ -298,6 +298,25 @@ class ConvGRU(nn.Module):
         return out
 
 
+def convgru_fused_pack(gru, h, w):
+    """Launch-lean form of the ConvGRU step (weights only): gates_conv(cat[x, matching(h_prev)]) is one 3x3 convolution of
+    cat[x, h_prev] with the matching layer composed into the hidden half of the weights, plus a per-pixel map that carries
+    the gates bias and the matching bias as seen through the zero-padded convolution.  -> (W' [3C, 2C, 3, 3], map [3C, h, w])."""
+    cell = gru.convGRUCell
+    C = cell.hidden_channels
+    dev = cell.gates_conv.weight.device
+    wg = cell.gates_conv.weight.detach().double().cpu()          # (float64 on the host: a one-off, weights only)
+    bg = cell.gates_conv.bias.detach().double().cpu() if cell.gates_conv.bias is not None else wg.new_zeros(wg.shape[0])
+    m = cell.matching_layer.weight.detach().double().cpu()[:, :, 0, 0]
+    bm = cell.matching_layer.bias.detach().double().cpu() if cell.matching_layer.bias is not None else m.new_zeros(m.shape[0])
+    if wg.shape[1] != 2 * C or m.shape != (C, C):
+        return None, None
+    wgx, wgh = wg[:, :C], wg[:, C:]
+    wp = torch.cat([wgx, torch.einsum("omkl,mc->ockl", wgh, m)], dim=1).float().contiguous()
+    bmap = F.conv2d(bm.view(1, C, 1, 1).expand(1, C, h, w).contiguous(), wgh, bg, padding=1)[0].float().contiguous()
+    return wp.to(dev), bmap.to(dev)
+
+
 class RadarBEVTemporalEncoder(nn.Module):
     """racformer_transformer.py:618-663"""
 
@@ -331,12 +350,16 @@ class RadarBEVTemporalEncoder(nn.Module):
         Tv = min(4, T)
         if not (down.is_cuda and down.dtype == torch.float32 and r == 2 and Tv < T):
             return self.upsample(gru.flatten(0, 1))
-        # ConvGRU leaves the frames t >= 4 at zero (:674-693): their upsample is zero and the 3x3 convolution of an
-        # all-zero map is exactly its bias, so only the first frames go through the resize (one HIP launch instead
-        # of torch's generic kernel) and the convolution.
+        return self.hidden_from_gru(gru[:, :Tv], T, H, W)
+
+    def hidden_from_gru(self, gru_live, T, H, W):
+        """ConvGRU leaves the frames t >= 4 at zero (:674-693): their upsample is zero and the 3x3 convolution of an
+        all-zero map is exactly its bias, so only the live frames [B,Tv,hidden,H/2,W/2] go through the resize (one HIP
+        launch instead of torch's generic kernel) and the convolution.  -> [B*T,hidden,H,W]."""
+        B, Tv = gru_live.shape[:2]
         conv = self.upsample[1]
-        hv = conv(upsample2x_fused(gru[:, :Tv].reshape(B * Tv, self.hidden_dims, H // r, W // r)))
-        hid = torch.empty(B, T, self.hidden_dims, H, W, device=down.device, dtype=down.dtype)
+        hv = conv(upsample2x_fused(gru_live.reshape(B * Tv, self.hidden_dims, H // 2, W // 2)))
+        hid = torch.empty(B, T, self.hidden_dims, H, W, device=gru_live.device, dtype=gru_live.dtype)
         hid[:, :Tv] = hv.view(B, Tv, self.hidden_dims, H, W)
         hid[:, Tv:] = (conv.bias if conv.bias is not None else hv.new_zeros(self.hidden_dims)).view(1, 1, -1, 1, 1)
         return hid.flatten(0, 1)
@@ -352,13 +375,21 @@ class RadarBEVTemporalEncoder(nn.Module):
     # output already channel-last for value_proj.
     fused_conv = True
 
-    def downsample_pack(self):
-        """Packed weights of the stride-2 downsample convolution for rac_conv3x3s2_fwd ({} if not 3x3 / 64 channels)."""
+    def downsample_pack(self, H=None, W=None):
+        """Packed weights of the stride-2 downsample convolution for rac_conv3x3s2_fwd ({} if not 3x3 / 64 channels) and,
+        for H x W input maps, the launch-lean ConvGRU operands (convgru_fused_pack)."""
         d = self.downsample
         if self.hidden_dims != 64 or d.kernel_size != (3, 3) or d.stride != (2, 2) or d.padding != (1, 1):
             return {}
         ws, alpha = pack_conv3x3_weight(d.weight, cout=64)
-        return dict(down_ws=ws, down_alpha=alpha) if ws is not None else {}
+        if ws is None:
+            return {}
+        pack = dict(down_ws=ws, down_alpha=alpha)
+        if H is not None and self.convGRU.convGRUCell.gates_conv.kernel_size == (3, 3):
+            gw, gmap = convgru_fused_pack(self.convGRU, H // 2, W // 2)
+            if gw is not None:
+                pack.update(gru_w=gw, gru_bmap=gmap)
+        return pack
 
     def hidden_bound(self):
         """Upper bound of |hidden_stream(.)[1]| from the weights of the last convolution (inputs bounded by 1)."""
@@ -387,13 +418,29 @@ class RadarBEVTemporalEncoder(nn.Module):
         else:
             x = bev_feats.flatten(0, 1).contiguous()
             img.begin([x], packed["bound"]).pack(x, 0)
-            if packed.get("down_ws") is not None and self.downsample_ratio == 2 and ((H // 2) * (W // 2)) % 128 == 0:
-                # downsample (3x3, stride 2) on the image that is being built for the fusion convolution anyway
-                down = img.conv_s2(packed["down_ws"], packed["down_alpha"], self.downsample.bias, C)
-                down = down.view(B, T, self.hidden_dims, H // 2, W // 2)
+            hd, Tv = self.hidden_dims, min(4, T)
+            own_down = packed.get("down_ws") is not None and self.downsample_ratio == 2 and ((H // 2) * (W // 2)) % 128 == 0
+            if own_down and packed.get("gru_w") is not None and Tv < T and tuple(packed["gru_bmap"].shape[1:]) == (H // 2, W // 2):
+                # launch-lean ConvGRU: the downsample kernel writes the x half of every step's convolution input
+                # [x_t | h_{t-1}], the gate kernel writes h_t into the next step's hidden half: per step one library
+                # convolution + one HIP launch (matching layer, concatenation and bias adds are composed / folded)
+                xh = torch.empty(B, T, 2 * hd, H // 2, W // 2, device=x.device, dtype=torch.float32)
+                xh[:, 0, hd:].zero_()
+                img.conv_s2(packed["down_ws"], packed["down_alpha"], self.downsample.bias, C, out=xh.view(B * T, 2 * hd, H // 2, W // 2))
+                live = torch.empty(B, Tv, hd, H // 2, W // 2, device=x.device, dtype=torch.float32)
+                for t in range(Tv):
+                    gates = F.conv2d(xh[:, t], packed["gru_w"], None, padding=1)
+                    gru_gate_fused(gates, xh[:, t, hd:], live[:, t], bias_map=packed["gru_bmap"],
+                                   h_out2=xh[:, t + 1, hd:] if t + 1 < Tv else None)
+                hid = self.hidden_from_gru(live, T, H, W)
             else:
-                down = self.downsample(x).reshape(B, T, self.hidden_dims, H // self.downsample_ratio, W // self.downsample_ratio)
-            hid = self.hidden_from_down(down, H, W)
+                if own_down:
+                    # downsample (3x3, stride 2) on the image that is being built for the fusion convolution anyway
+                    down = img.conv_s2(packed["down_ws"], packed["down_alpha"], self.downsample.bias, C)
+                    down = down.view(B, T, hd, H // 2, W // 2)
+                else:
+                    down = self.downsample(x).reshape(B, T, hd, H // self.downsample_ratio, W // self.downsample_ratio)
+                hid = self.hidden_from_down(down, H, W)
         img.pack(hid.contiguous(), C)
         return img.conv(packed["ws"], packed["alpha"], None if pb is not None else self.temporal_fusion.bias, pb)
 
@@ -533,7 +580,7 @@ class BEVSampling(nn.Module):
             return {}
         pos = self.positional_encoding.grid(H, W).detach().double().reshape(-1, H * W)            # [C, HW]
         pixel_bias = (pos.t() @ wv.t() + (wv @ bc + bv)).float().contiguous()                          # [HW, C]
-        return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), pixel_bias=pixel_bias, **te.downsample_pack())
+        return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), pixel_bias=pixel_bias, **te.downsample_pack(H, W))
 
     def keypoints(self, query_ray, query_feat, time_diff, d_region):
         """-> loc [B,Q,heads,T,P,2] in [0,1], weights [B,Q,heads,T,1,P] (:490-529)."""
@@ -836,8 +883,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         conv_pack = None
         if radar_bev_feats.is_cuda and self.fused and te.fused_conv:
             Hr, Wr = radar_bev_feats.shape[-2:]
-            conv_params = [te.temporal_fusion.weight, up.weight, te.downsample.weight] + \
-                [m.bias for m in (te.temporal_fusion, up) if m.bias is not None]
+            cell = te.convGRU.convGRUCell
+            conv_params = [te.temporal_fusion.weight, up.weight, te.downsample.weight, cell.gates_conv.weight,
+                           cell.matching_layer.weight] + \
+                [m.bias for m in (te.temporal_fusion, up, cell.gates_conv, cell.matching_layer) if m.bias is not None]
             if self.compose_radar_value:
                 pe_, vp = rbs.positional_encoding, rbs.attention.value_proj
                 conv_pack = self._cached(f"conv_value_pack_{Hr}x{Wr}", conv_params + [vp.weight, vp.bias, pe_.row_embed.weight,
@@ -846,8 +895,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             if not conv_pack:
                 def plain_pack():
                     ws, alpha = pack_conv3x3_weight(te.temporal_fusion.weight)
-                    return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), **te.downsample_pack())
-                conv_pack = self._cached("conv_pack", conv_params, plain_pack)
+                    return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), **te.downsample_pack(Hr, Wr))
+                conv_pack = self._cached(f"conv_pack_{Hr}x{Wr}", conv_params, plain_pack)
         lbs = self.sampling_lss_bev
         if lss_bev_feats.is_cuda and self.fused:
             # the positional term value_proj(pos) of the LSS stream depends on weights only: built once, not per forward

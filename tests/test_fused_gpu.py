@@ -315,8 +315,21 @@ def test_temporal_encoder_fused_pieces():
         ref = enc(bev)                                                     # CPU: the reference decomposition
         eg = enc.to(DEV)
         ws, alpha = pack_conv3x3_weight(eg.temporal_fusion.weight)
-        got = eg.forward_channel_last(bev.to(DEV), dict(ws=ws, alpha=alpha, bound=eg.hidden_bound(), **eg.downsample_pack()))
+        got = eg.forward_channel_last(bev.to(DEV), dict(ws=ws, alpha=alpha, bound=eg.hidden_bound(), **eg.downsample_pack(16, 16)))
     assert (got.permute(0, 3, 1, 2).cpu() - ref[0]).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
+    # 32 x 32 maps: the stride-2 kernel and the launch-lean ConvGRU (composed matching layer, bias map) are on the path
+    enc2 = RadarBEVTemporalEncoder(256, 64, 8).eval()
+    for mod in (enc2.convGRU.convGRUCell.gates_conv, enc2.convGRU.convGRUCell.matching_layer, enc2.downsample):
+        torch.nn.init.normal_(mod.bias, std=0.2)
+    bev2 = torch.randn(1, 8, 256, 32, 32) * 0.5
+    with torch.no_grad():
+        ref2 = enc2(bev2)
+        eg2 = enc2.to(DEV)
+        ws2, alpha2 = pack_conv3x3_weight(eg2.temporal_fusion.weight)
+        pack2 = dict(ws=ws2, alpha=alpha2, bound=eg2.hidden_bound(), **eg2.downsample_pack(32, 32))
+        assert "gru_w" in pack2 and "down_ws" in pack2
+        got2 = eg2.forward_channel_last(bev2.to(DEV), pack2)
+    assert (got2.permute(0, 3, 1, 2).cpu() - ref2[0]).abs().max().item() < 2e-5 * ref2.abs().max().item() + 1e-5
 
 
 @pytest.mark.parametrize("rows", [900, 37])

@@ -26,6 +26,7 @@
  *   rac_layer_tail_fwd<- decoder-layer tail (projections, norms, fusion, FFN, branches, refine), one launch
  *                        models/racformer_transformer.py:249-269
  *   rac_add_ln_fwd    <- residual add + nn.LayerNorm (+ReLU) groups, models/racformer_transformer.py:170-258
+ *   rac_layer_boundary_fwd <- rac_refine_fwd + rac_box_prep_fwd + rac_pe_head_fwd of consecutive layers, one launch
  *   rac_refine_fwd    <- refine_bbox + velocity scaling + theta_d2xy_coods of the outputs
  *                        models/racformer_transformer.py:230-236,265-269,134
  *   rac_mixing_fwd    <- AdaptiveMixing.inner_forward's matmul / layer_norm / relu chain
@@ -192,6 +193,14 @@ int rac_pe_head_fwd(const float *x, int ld_x, const float *weight, const float *
  *   bbox_pred [B*Q,10] (polar, next layer's input), bbox_xy [B*Q,10] (normalised xy, the layer's output). */
 int rac_refine_fwd(const float *proposal, const float *delta, const float *time_diff_safe, float *bbox_pred,
                    float *bbox_xy, int B, int Q, int T, float num_ray, void *stream);
+
+/* Boundary between two decoder layers in one launch: rac_refine_fwd for the finished layer and, for the boxes it produces,
+ * the first two launches of the next layer -- rac_box_prep_fwd (box_table [B*Q,8]) and rac_pe_head_fwd (pe_out [B*Q,256]
+ * = relu(LayerNorm(pe_weight (theta,d,z) + pe_bias))).  Same arithmetic as the three separate entry points. */
+int rac_layer_boundary_fwd(const float *proposal, const float *delta, const float *time_diff_safe, float *bbox_pred,
+                           float *bbox_xy, float *box_table, const float *pc_range, const float *pe_weight,
+                           const float *pe_bias, const float *pe_gamma, const float *pe_beta, float *pe_out, int B, int Q,
+                           int T, int dim, float num_ray, float eps, void *stream);
 
 /* Matrix-core arithmetic of rac_mixing_fwd. */
 enum {

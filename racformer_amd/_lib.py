@@ -32,6 +32,7 @@ SIGNATURES = {
     "rac_layer_tail_fwd": (_i, [_vp, _vp, _i, ctypes.c_int64] + [_i] * 5 + [_f, _f, _vp]),
     "rac_add_ln_fwd": (_i, [_vp, _i, ctypes.c_int64, _i, _f] + [_vp] * 6 + [_i, _i, _i, _f, _i, _vp, _f, _i, _vp]),
     "rac_pe_head_fwd": (_i, [_vp, _i] + [_vp] * 5 + [_i, _i, _f, _vp]),
+    "rac_layer_boundary_fwd": (_i, [_vp] * 12 + [_i] * 4 + [_f, _f, _vp]),
     "rac_refine_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_f, _vp]),
     "rac_mixing_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _f] + [_i] * 6 + [_f, _i, _vp]),
     "rac_sasa_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),

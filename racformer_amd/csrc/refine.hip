@@ -63,3 +63,99 @@ extern "C" int rac_refine_fwd(const float *proposal, const float *delta, const f
                        time_diff_safe, bbox_pred, bbox_xy, n, Q, T, num_ray);
     return rac_launch_status("rac_refine_fwd");
 }
+
+// ------------------------------------------------------------------------------------------------ layer boundary
+// One launch at the boundary between two decoder layers: refine_bbox of the finished layer (as refine_kernel) and, for
+// the boxes it produces, what the next layer computes first: the per-query box table (box_prep_kernel) and the head of the
+// position encoder relu(LN(W x + b)) on (theta, d, z) (pe_head_kernel).  One wave per query: every lane evaluates the
+// (cheap, identical) box arithmetic, lane 0 stores it, then the wave does the 256-wide LayerNorm.
+__device__ __forceinline__ float lb_wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layer_boundary_kernel(const float *__restrict__ prop, const float *__restrict__ delta,
+                                                             const float *__restrict__ td_safe, float *__restrict__ pred,
+                                                             float *__restrict__ xy, float *__restrict__ table,
+                                                             const float *__restrict__ W, const float *__restrict__ bias,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float *__restrict__ h_out, int n, int Q, int T, float num_ray,
+                                                             float eps, float p0, float p1, float p2, float sx, float sy, float sz)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n)
+        return;
+    const float *p = prop + (size_t)i * 10, *d = delta + (size_t)i * 10;
+    float o[10];
+    o[0] = p[0] + (ref_sigmoid(d[0]) * 2.f - 1.f) / num_ray;
+    o[1] = ref_sigmoid(d[1] + ref_inverse_sigmoid(p[1]));
+    o[2] = ref_sigmoid(d[2] + ref_inverse_sigmoid(p[2]));
+#pragma unroll
+    for (int k = 3; k < 10; ++k)
+        o[k] = d[k];
+    if (T > 1) {
+        const float td = td_safe[(i / Q) * T + 1];
+        o[8] = o[8] / td;
+        o[9] = o[9] / td;
+    }
+    const float ang = o[0] * REF_TWO_PI, rad = o[1] * 65.0f;
+    const float xn = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f);
+    const float yn = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f);
+    if (lane == 0) {
+        float *pp = pred + (size_t)i * 10, *px = xy + (size_t)i * 10, *t = table + (size_t)i * 8;
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+            pp[k] = o[k];
+        px[0] = xn;
+        px[1] = yn;
+#pragma unroll
+        for (int k = 2; k < 10; ++k)
+            px[k] = o[k];
+        const float yaw = atan2f(o[6], o[7]);
+        t[0] = xn * sx + p0;
+        t[1] = yn * sy + p1;
+        t[2] = o[2] * sz + p2;
+        t[3] = expf(o[3]);
+        t[4] = expf(o[4]);
+        t[5] = expf(o[5]);
+        t[6] = cosf(yaw);
+        t[7] = sinf(yaw);
+    }
+    // position-encoder head on (theta, d, z) of the refined box (as pe_head_kernel)
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + j;
+        v[j] = W[c * 3] * o[0] + W[c * 3 + 1] * o[1] + W[c * 3 + 2] * o[2] + bias[c];
+    }
+    const float mean = lb_wave_sum((v[0] + v[1]) + (v[2] + v[3])) / 256.f;
+    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    const float rstd = 1.f / sqrtf(lb_wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 256.f + eps);
+    const rac_f4 g = rac_ld4(gamma + lane * 4), b = rac_ld4(beta + lane * 4);
+    rac_f4 y = {fmaxf(d0 * rstd * g.x + b.x, 0.f), fmaxf(d1 * rstd * g.y + b.y, 0.f), fmaxf(d2 * rstd * g.z + b.z, 0.f),
+                fmaxf(d3 * rstd * g.w + b.w, 0.f)};
+    *reinterpret_cast<rac_f4 *>(h_out + (size_t)i * 256 + lane * 4) = y;
+}
+
+extern "C" int rac_layer_boundary_fwd(const float *proposal, const float *delta, const float *time_diff_safe, float *bbox_pred,
+                                      float *bbox_xy, float *box_table, const float *pc_range, const float *pe_weight,
+                                      const float *pe_bias, const float *pe_gamma, const float *pe_beta, float *pe_out, int B,
+                                      int Q, int T, int dim, float num_ray, float eps, void *stream)
+{
+    RAC_CHECK_ARG(B >= 0 && Q >= 0 && T >= 1 && num_ray > 0.f && dim == 256, "rac_layer_boundary_fwd: bad sizes B=%d Q=%d T=%d dim=%d", B, Q, T, dim);
+    if (B * Q == 0)
+        return 0;
+    RAC_CHECK_ARG(proposal && delta && time_diff_safe && bbox_pred && bbox_xy && box_table && pc_range && pe_weight && pe_bias &&
+                      pe_gamma && pe_beta && pe_out,
+                  "rac_layer_boundary_fwd: null pointer");
+    const int n = B * Q;
+    hipLaunchKernelGGL(layer_boundary_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, proposal, delta,
+                       time_diff_safe, bbox_pred, bbox_xy, box_table, pe_weight, pe_bias, pe_gamma, pe_beta, pe_out, n, Q, T,
+                       num_ray, eps, pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1],
+                       pc_range[5] - pc_range[2]);
+    return rac_launch_status("rac_layer_boundary_fwd");
+}

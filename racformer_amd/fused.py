@@ -189,6 +189,25 @@ SPLIT_BIAS_PAD = 64      # extra K columns of a split image that carry the bias 
 SPLIT_SLICE = 2048       # K slice of rac_mixing_fwd's out_split image = split-K batch of out_proj
 
 
+def layer_boundary_fused(proposal, delta, time_diff_safe, num_ray, pc_range, pe_linear, pe_norm):
+    """refine_fused + box_prep + pe_head for the refined boxes in one launch (rac_layer_boundary_fwd).
+    -> (bbox_pred [B,Q,10], bbox_xy [B,Q,10], box_table [B,Q,8], pe_head output [B,Q,256])."""
+    proposal, delta = proposal.contiguous(), delta.contiguous()
+    _lib.require_gpu(proposal, delta, time_diff_safe, what="layer_boundary_fused")
+    B, Q, _ = proposal.shape
+    pred, xy = torch.empty_like(proposal), torch.empty_like(proposal)
+    table = torch.empty(B, Q, 8, device=proposal.device, dtype=torch.float32)
+    h = torch.empty(B, Q, pe_linear.weight.shape[0], device=proposal.device, dtype=torch.float32)
+    pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    rc = _lib.lib().rac_layer_boundary_fwd(_lib.ptr(proposal), _lib.ptr(delta), _lib.ptr(time_diff_safe), _lib.ptr(pred),
+                                           _lib.ptr(xy), _lib.ptr(table), pc, _lib.ptr(pe_linear.weight), _lib.ptr(pe_linear.bias),
+                                           _lib.ptr(pe_norm.weight), _lib.ptr(pe_norm.bias), _lib.ptr(h), B, Q,
+                                           time_diff_safe.shape[1], pe_linear.weight.shape[0], float(num_ray), float(pe_norm.eps),
+                                           _lib.stream_ptr())
+    _lib.check(rc, "rac_layer_boundary_fwd")
+    return pred, xy, table, h
+
+
 def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=None, out=None, split=False, a_scale=1.0):
     """[relu](LayerNorm(a_scale * sum_s a[s] + residual + bias)) [+ post] with ``norm`` an nn.LayerNorm; a is [..., dim]
     (unit inner stride; rows may be a column slice of a wider tensor) or [S, ..., dim] with num_partials=S.

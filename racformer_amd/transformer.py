@@ -25,7 +25,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, gemm_f16x3, pack_gemm_weight_f16x3, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, row_gemm, row_seg, rowgemm_launch, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, gemm_f16x3, layer_boundary_fused,
+                    pack_gemm_weight_f16x3, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, row_gemm, row_seg, rowgemm_launch, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
                     pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
 from .msda import msda_forward
 from .msmv import msmv_forward
@@ -827,6 +828,9 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # K-concatenated images.  Measured 158 us against 130 us (8 K-steps per 256x256 tile: the two-stage register pipeline
         # of the convolution kernel does not hide the first-load and store latencies of so short a K loop), so it is off.
         self.own_gemm = False
+        # ((next layer index, box pointer, shape), pe_head output, box table) handed from a layer's boundary launch to the next
+        # call; the decoder clears it before layer 0, and it is only honoured for the matching layer index and tensor
+        self._carry = None
         # radar stream: value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack)
         self.compose_radar_value = True
         self._pack_cache = {}
@@ -951,15 +955,19 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)   # noqa: E731
         pe, p = self.position_encoder, self.self_attn.attention.attn
         packs = prepared.get("split_packs")
-        # position encoder: relu(LN(Linear(3->256))) in one kernel, second Linear raw
-        h = pe_head(qb[..., :3], pe[0], pe[1])
+        # position encoder: relu(LN(Linear(3->256))) in one kernel (for layers > 0 already produced, with the box table, by
+        # the previous layer's boundary launch), second Linear raw
+        carried = self._carry if self._carry is not None and self._carry[0] == (layer, qb.data_ptr(), tuple(qb.shape)) else None
+        self._carry = None
+        h = carried[1] if carried is not None else pe_head(qb[..., :3], pe[0], pe[1])
         y2 = new(n, E)
         rowgemm_launch([row_gemm([row_seg(h)], pe[3].weight, pe[3].bias, y2)], n)
         # x = query_feat + relu(LN(y2));  q|k|v|tau = x @ [in_proj; gen_tau]^T
         x, lin = new(B, Q, E), new(B, Q, 3 * E + self.self_attn.num_heads)
         rowgemm_launch([row_gemm([row_seg(y2, norm=pe[4], relu=True, post=query_feat.contiguous(), x_out=x)],
                                  prepared["sasa_w"][0], prepared["sasa_w"][1], lin)], n)
-        table = box_prep(qb, self.pc_range)      # decode_bbox(theta_d2xy(.)) once for SASA and the 3 sampling kernels
+        # decode_bbox(theta_d2xy(.)) once for SASA and the 3 sampling kernels
+        table = carried[2] if carried is not None else box_prep(qb, self.pc_range)
         o = sasa_fused(lin[..., :3 * E], lin[..., 3 * E:], qb, self.self_attn.num_heads, self.pc_range, box_table=table)
         attn = new(n, E)
         rowgemm_launch([row_gemm([row_seg(o)], p.out_proj.weight, p.out_proj.bias, attn)], n)
@@ -1019,7 +1027,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         cls_score, delta = new(B, Q, self.num_classes), new(B, Q, self.code_size)
         rowgemm_launch([row_gemm([row_seg(c3, norm=cb[4], relu=True)], cb[6].weight, cb[6].bias, cls_score),
                         row_gemm([row_seg(r2)], rg[4].weight, rg[4].bias, delta)], n)
-        bbox_pred, bbox_xy = refine_fused(qb, delta, meta["time_diff_safe"], self.num_ray)
+        # refine_bbox of this layer + box table and position-encoder head of the next one, one launch
+        bbox_pred, bbox_xy, next_table, next_h = layer_boundary_fused(qb, delta, meta["time_diff_safe"], self.num_ray,
+                                                                      self.pc_range, pe[0], pe[1])
+        self._carry = ((layer + 1, bbox_pred.data_ptr(), tuple(bbox_pred.shape)), next_h, next_table)
         if stages is not None:
             mixed = x1 + p_scale * partials.sum(0).view_as(x1) + self.mixing.out_proj.bias
             stages.update(position_encoder=x - query_feat, self_attn=x + attn.view_as(x),
@@ -1268,6 +1279,7 @@ class RaCFormerTransformerDecoder(nn.Module):
             for lvl, g in enumerate(grouped):
                 mlvl_feats[lvl] = g  # the reference mutates the caller's list too (:124)
         prepared = self.decoder_layer.prepare(lss_bev_feats, radar_bev_feats, radar_hidden)
+        self.decoder_layer._carry = None
         cls_scores, bbox_preds = [], []
         for i in range(self.num_layers):
             st = {} if stages_per_layer is not None else None

@@ -485,3 +485,18 @@ def test_conv3x3_stride2_kernel(shape):
         else:
             want, tol = conv.to(DEV)(xg).double().cpu(), 2e-5
     assert (got.double().cpu() - want).abs().max().item() <= tol * want.abs().max().item()
+
+
+def test_layer_boundary_kernel_matches_separate_launches():
+    """rac_layer_boundary_fwd == rac_refine_fwd followed by rac_box_prep_fwd and rac_pe_head_fwd on the refined boxes."""
+    from racformer_amd.fused import box_prep, layer_boundary_fused, pe_head, refine_fused
+    torch.manual_seed(17)
+    B, Q, T = 2, 37, 3
+    prop, delta = torch.rand(B, Q, 10, device=DEV), torch.randn(B, Q, 10, device=DEV)
+    td = torch.tensor([[1.0, 0.5, 1.0], [1.0, 1.0, 1.5]], device=DEV)
+    lin, ln = torch.nn.Linear(3, 256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
+    pred, xy, table, h = layer_boundary_fused(prop, delta, td, 150, syn.PC_RANGE, lin, ln)
+    pred0, xy0 = refine_fused(prop, delta, td, 150)
+    assert torch.equal(pred, pred0) and torch.equal(xy, xy0)
+    assert (table - box_prep(pred0, syn.PC_RANGE)).abs().max().item() < 1e-6
+    assert (h - pe_head(pred0[..., :3], lin, ln)).abs().max().item() < 1e-5

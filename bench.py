@@ -48,6 +48,7 @@ def build_head(cfg, device, feature_dtype=torch.float32):
     head.transformer.decoder.feature_dtype = feature_dtype
     head.transformer.decoder.overlap_prepare = os.environ.get("RAC_OVERLAP_PREPARE", "0") != "0"   # experiment switch
     head.transformer.decoder.decoder_layer.own_gemm = os.environ.get("RAC_OWN_GEMM", "0") != "0"   # experiment switch
+    head.transformer.decoder.decoder_layer.bev_two_streams = os.environ.get("RAC_BEV_TWO_STREAMS", "0") != "0"
     return head.eval().to(device)
 
 

@@ -831,6 +831,9 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # ((next layer index, box pointer, shape), pe_head output, box table) handed from a layer's boundary launch to the next
         # call; the decoder clears it before layer 0, and it is only honoured for the matching layer index and tensor
         self._carry = None
+        # the radar and the LSS BEV kernel of a layer on two HIP streams (see forward_fused).  Measured 156.5 vs 160.5 samples/s:
+        # the two kernels contend for the same L2 / Infinity-Cache bandwidth and the stream joins cost more than the overlap; off.
+        self.bev_two_streams = False
         # radar stream: value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack)
         self.compose_radar_value = True
         self._pack_cache = {}
@@ -984,12 +987,26 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         r_off, r_ray, r_sc, r_qu = lin[3:7]
         l_off, l_ray, l_sc, l_qu = lin[7:11]
         bev = new(2, B, Q, E)
+        side = prepared.get("side_stream") if self.bev_two_streams else None
+        if side is not None:
+            # the two BEV launches are independent and each is one round of workgroups with a latency-bound prologue and
+            # tail: on two streams the second kernel's workgroups fill the CUs as the first one's drain
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            bev.record_stream(side)
+            with torch.cuda.stream(side):
+                bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
+                                   lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
+                                   box_table=table, out=bev[1])
         bev_sampling_fused(prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff,
                            rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region,
                            box_table=table, out=bev[0])
-        bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
-                           lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
-                           box_table=table, out=bev[1])
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
+                               lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
+                               box_table=table, out=bev[1])
         sampled_feat = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=lin[0:3],
                                      box_table=table)
         partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)

@@ -828,8 +828,9 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # K-concatenated images.  Measured 158 us against 130 us (8 K-steps per 256x256 tile: the two-stage register pipeline
         # of the convolution kernel does not hide the first-load and store latencies of so short a K loop), so it is off.
         self.own_gemm = False
-        # ((next layer index, box pointer, shape), pe_head output, box table) handed from a layer's boundary launch to the next
-        # call; the decoder clears it before layer 0, and it is only honoured for the matching layer index and tensor
+        # ((next layer index, box pointer, shape, version), pe_head output, box table, the box tensor) handed from a layer's
+        # boundary launch to the next call; the decoder clears it before layer 0, and it is only honoured for the matching
+        # layer index and (live, unmodified) tensor
         self._carry = None
         # the radar and the LSS BEV kernel of a layer on two HIP streams (see forward_fused).  Measured 156.5 vs 160.5 samples/s:
         # the two kernels contend for the same L2 / Infinity-Cache bandwidth and the stream joins cost more than the overlap; off.
@@ -837,6 +838,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # radar stream: value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack)
         self.compose_radar_value = True
         self._pack_cache = {}
+        self.capture_loc = None   # a list: every layer appends the sampling kernel's own locations (see _sample)
 
     def _cached(self, key, params, fn):
         """Weight-derived operands (concatenations, re-layouts, f16 splits) are functions of the parameters only:
@@ -864,6 +866,17 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         dz_new = torch.sigmoid(bbox_delta[..., 1:3] + inverse_sigmoid(bbox_proposal[..., 1:3]))
         theta = bbox_proposal[..., 0:1] + (torch.sigmoid(bbox_delta[..., 0:1]) * 2 - 1) / self.num_ray
         return torch.cat([theta, dz_new, bbox_delta[..., 3:]], dim=-1)
+
+    def _sample(self, qb, x1, mlvl_feats, img_metas, d_region, linear_out, table):
+        """The fused sampling launch; with ``capture_loc`` set to a list, the kernel also writes the locations it sampled at
+        ((u, v, view / (N-1)) per point, [S,Q,P,3] -- the reference's DUMP hook, sparsebev_sampling.py:82-87) and they are
+        appended to it: the parity tests use them to attribute first-valid-view flips."""
+        if self.capture_loc is None:
+            return self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=linear_out, box_table=table)
+        out, loc, _ = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=linear_out, box_table=table,
+                                    debug=True)
+        self.capture_loc.append(loc)
+        return out
 
     def _side_stream(self, device):
         if getattr(self, "_side", None) is None or self._side.device != device:
@@ -960,7 +973,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         packs = prepared.get("split_packs")
         # position encoder: relu(LN(Linear(3->256))) in one kernel (for layers > 0 already produced, with the box table, by
         # the previous layer's boundary launch), second Linear raw
-        carried = self._carry if self._carry is not None and self._carry[0] == (layer, qb.data_ptr(), tuple(qb.shape)) else None
+        carried = self._carry if self._carry is not None and self._carry[0] == (layer, qb.data_ptr(), tuple(qb.shape), qb._version) \
+            else None
         self._carry = None
         h = carried[1] if carried is not None else pe_head(qb[..., :3], pe[0], pe[1])
         y2 = new(n, E)
@@ -1007,8 +1021,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
                                lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
                                box_table=table, out=bev[1])
-        sampled_feat = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=lin[0:3],
-                                     box_table=table)
+        sampled_feat = self._sample(qb, x1, mlvl_feats, img_metas, d_region, lin[0:3], table)
         partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)
         p_scale = packs["out_alpha"] if packs else 1.0
         # both BEV output projections in one launch
@@ -1047,7 +1060,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # refine_bbox of this layer + box table and position-encoder head of the next one, one launch
         bbox_pred, bbox_xy, next_table, next_h = layer_boundary_fused(qb, delta, meta["time_diff_safe"], self.num_ray,
                                                                       self.pc_range, pe[0], pe[1])
-        self._carry = ((layer + 1, bbox_pred.data_ptr(), tuple(bbox_pred.shape)), next_h, next_table)
+        # (the carry holds bbox_pred itself: its storage cannot be freed and handed to another tensor while the key is live)
+        self._carry = ((layer + 1, bbox_pred.data_ptr(), tuple(bbox_pred.shape), bbox_pred._version), next_h, next_table, bbox_pred)
         if stages is not None:
             mixed = x1 + p_scale * partials.sum(0).view_as(x1) + self.mixing.out_proj.bias
             stages.update(position_encoder=x - query_feat, self_attn=x + attn.view_as(x),
@@ -1102,8 +1116,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
                            lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
                            box_table=table, out=bev[1])
-        sampled_feat = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=lin[0:3],
-                                     box_table=table)
+        sampled_feat = self._sample(qb, x1, mlvl_feats, img_metas, d_region, lin[0:3], table)
         # adaptive mixing: generator GEMM -> MFMA kernel -> split-K partial products of out_proj
         if side is not None:
             torch.cuda.current_stream().wait_event(done)
@@ -1163,8 +1176,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
                                                                 prepared["radar_hw"], time_diff, d_region, lin[3:7], table)
             lss_raw = self.sampling_lss_bev.attend_prepared(qb, query_feat, prepared["lss_value"],
                                                             prepared["lss_hw"], time_diff, d_region, lin[7:11], table)
-            sampled_feat = self.sampling(qb, query_feat, mlvl_feats, img_metas, d_region=d_region,
-                                         linear_out=lin[0:3], box_table=table)
+            sampled_feat = self._sample(qb, query_feat, mlvl_feats, img_metas, d_region, lin[0:3], table)
         else:
             radar_raw = self.sampling_radar_bev.attend_prepared_unfused(
                 query_bbox, query_feat, prepared["radar_value"], prepared["radar_hw"], time_diff, d_region)
@@ -1241,31 +1253,40 @@ class RaCFormerTransformerDecoder(nn.Module):
         self.decoder_layer.init_weights()
 
     def stage_metas(self, img_metas, B, device):
-        """Host-side numerics of :99-109 (float64 timestamps -> float32 time_diff; lidar2img),
-        one upload each; also the clamped divisor of :266-269."""
+        """Host-side numerics of :99-109 (float64 timestamps -> float32 time_diff; lidar2img), one upload; also the
+        clamped divisor of :266-269.  Like the reference, metas[0] receives ``time_diff`` and a device ``lidar2img``; a
+        metas list that comes back with the same timestamps and its staged matrices is not staged again, one whose
+        timestamps changed gets a new ``time_diff`` (the reference recomputes on every forward)."""
         m0 = img_metas[0]
-        if isinstance(m0.get("lidar2img"), torch.Tensor) and "time_diff_safe" in m0:
-            return  # already staged by an earlier call with the same metas
         ts = np.array([m["img_timestamp"] for m in img_metas], dtype=np.float64)
+        l2i_staged = isinstance(m0.get("lidar2img"), torch.Tensor) and m0["lidar2img"].device == device \
+            and m0["lidar2img"].dim() == 4 and m0["lidar2img"].shape[0] == B
+        if l2i_staged and "time_diff_safe" in m0 and np.array_equal(m0.get("_rac_staged_ts"), ts):
+            return
+        m0["_rac_staged_ts"] = ts.copy()
         ts = np.reshape(ts, [B, -1, self.num_cams])
         td = np.mean(ts[:, :1, :] - ts, axis=-1).astype(np.float32)
         td_safe = td.copy()
         td_safe[td_safe < 1e-5] = 1.0
-        l2i = np.asarray([m["lidar2img"] for m in img_metas]).astype(np.float32)
+        parts = [td.ravel(), td_safe.ravel()]
+        l2i = None
+        if not l2i_staged:
+            l2i = np.asarray([m["lidar2img"].cpu().numpy() if isinstance(m["lidar2img"], torch.Tensor) else m["lidar2img"]
+                              for m in img_metas]).astype(np.float32)
+            parts.append(l2i.ravel())
+        flat = torch.from_numpy(np.concatenate(parts))
         if device.type == "cuda":
             # one pinned staging block, one asynchronous copy: a pageable .to(device) would block the host until the
             # stream has drained, i.e. serialise this sample's launches behind the previous sample's kernels
-            flat = np.concatenate([td.ravel(), td_safe.ravel(), l2i.ravel()])
-            host = torch.from_numpy(flat).pin_memory()    # (the caching host allocator keeps the block until the copy has run)
-            dev = host.to(device, non_blocking=True)
-            n0, n1 = td.size, td.size + td_safe.size
-            img_metas[0]["time_diff"] = dev[:n0].view(td.shape)
-            img_metas[0]["time_diff_safe"] = dev[n0:n1].view(td_safe.shape)
-            img_metas[0]["lidar2img"] = dev[n1:].view(l2i.shape)
-            return
-        img_metas[0]["time_diff"] = torch.from_numpy(td).to(device)
-        img_metas[0]["time_diff_safe"] = torch.from_numpy(td_safe).to(device)
-        img_metas[0]["lidar2img"] = torch.from_numpy(l2i).to(device)
+            # (the caching host allocator keeps the pinned block until the copy has run)
+            dev = flat.pin_memory().to(device, non_blocking=True)
+        else:
+            dev = flat.to(device)
+        n0, n1 = td.size, td.size + td_safe.size
+        m0["time_diff"] = dev[:n0].view(td.shape)
+        m0["time_diff_safe"] = dev[n0:n1].view(td_safe.shape)
+        if l2i is not None:
+            m0["lidar2img"] = dev[n1:].view(l2i.shape)
 
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
                 stages_per_layer=None):

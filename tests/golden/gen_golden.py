@@ -19,6 +19,16 @@ is written out.  What each file pins:
   backward_small.npz   gradients of msmv_sampling / multi_scale_deformable_attn through the CPU fallbacks
   decoder_small*.npz   full RaCFormerTransformer forward at reduced shapes + layer-0 stage outputs
   decoder_f8*.npz      full f8 shapes: cls/box outputs of all 6 layers + stage checksums
+  decoder_f8_s{1,2,3}.npz / decoder_f8_3cam_s1.npz
+                       more seeds at full shapes: cls/box of all layers + the camera index the reference selected for
+                       every sampling point of every layer (read at its msmv operator boundary), for flip attribution
+  decoder_f8_tf.npz    teacher-forcing fixture (seed 0): every layer's (query_bbox, query_feat) INPUT and its outputs,
+                       stage probes for 32 queries, selected views
+  decode_cases.npz     NMSFreeCoder.decode_single + RaCFormer_head.get_bboxes (nms_free_coder.py:37-88,
+                       racformer_head.py:488-507): crafted ties, centres outside post_center_range, scores around 0.05
+  head_small6.npz / head_f8.npz
+                       RaCFormer_head.forward (inference branch) + get_bboxes, and what _init_layers / generate_points
+                       put into init_query_bbox (racformer_head.py:51-79)
 """
 import argparse
 import os
@@ -186,11 +196,35 @@ STAGES = ["position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_b
           "mixing", "ffn"]
 
 
-def run_decoder(ref, cfg, seed, weight_seed, full_stages):
+class ViewTap:
+    """Reads, at the reference's msmv operator boundary (sparsebev_sampling.py:122-126), the camera index it selected for
+    every sampling point: the third location coordinate is i_view / (N - 1) (:110).  One uint8 [S,Q,P] array per call."""
+
+    def __init__(self, ref, num_cams):
+        self.mod, self.n, self.views, self.uv = ref.sparsebev_sampling, num_cams, [], []
+        self.orig = self.mod.msmv_sampling
+
+    def __enter__(self):
+        def tap(mlvl_feats, loc, w):
+            self.views.append(torch.round(loc[..., 2] * (self.n - 1)).to(torch.uint8).clone())
+            self.uv.append(loc[..., :2].clone())
+            return self.orig(mlvl_feats, loc, w)
+        self.mod.msmv_sampling = tap
+        return self
+
+    def __exit__(self, *exc):
+        self.mod.msmv_sampling = self.orig
+
+
+def run_decoder(ref, cfg, seed, weight_seed, full_stages, mode="stages"):
+    """mode "stages": cls/box + stage fixtures of layers 0 and 5 (the round-1 files); "seeds": cls/box + selected views
+    only; "tf": teacher-forcing fixture (per-layer inputs / outputs, stage probes, selected views)."""
     tr = ref.racformer_transformer.RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
     syn.fill_params(tr, weight_seed)
     layer = tr.decoder.decoder_layer
     captured = {}
+    if mode != "stages":
+        return run_decoder_views(ref, tr, cfg, seed, weight_seed, mode)
 
     def mk(name):
         def hook(mod, inp, out):
@@ -204,13 +238,13 @@ def run_decoder(ref, cfg, seed, weight_seed, full_stages):
     lss, radar = syn.make_bev(cfg, seed, 0), syn.make_bev(cfg, seed, 1)
     metas = syn.make_img_metas(cfg)
     t0 = time.time()
-    with torch.no_grad():
+    with torch.no_grad(), ViewTap(ref, cfg.num_cams) as tap:
         cls, box = tr(qb, qf, feats, lss, radar, None, metas)
     dt = time.time() - t0
     for h in hs:
         h.remove()
     out = dict(cls=cls, box=box, seed=np.array(seed), weight_seed=np.array(weight_seed),
-               ref_cpu_seconds=np.array(dt), time_diff=metas[0]["time_diff"])
+               ref_cpu_seconds=np.array(dt), time_diff=metas[0]["time_diff"], views=torch.stack(tap.views))
     for s, lst in captured.items():
         for li in (0, len(lst) - 1):
             t = lst[li]
@@ -227,6 +261,163 @@ def run_decoder(ref, cfg, seed, weight_seed, full_stages):
     return out, dt
 
 
+TF_PROBE = 32      # queries (evenly strided) whose stage outputs the teacher-forcing fixture keeps
+TF_PROBE_S = 4     # ... and for the [Q,4,96,64] sampled features
+
+
+def run_decoder_views(ref, tr, cfg, seed, weight_seed, mode):
+    layer = tr.decoder.decoder_layer
+    stage_out, layer_in, layer_out = {}, [], []
+
+    def mk(name):
+        def hook(mod, inp, out):
+            stage_out.setdefault(name, []).append(out.detach().clone())
+        return hook
+
+    hs = [getattr(layer, s).register_forward_hook(mk(s)) for s in STAGES] if mode == "tf" else []
+    hs.append(layer.register_forward_pre_hook(lambda m, a: layer_in.append((a[0].detach().clone(), a[1].detach().clone()))))
+    hs.append(layer.register_forward_hook(lambda m, a, o: layer_out.append(tuple(t.detach().clone() for t in o))))
+    qb, qf = syn.make_queries(cfg, seed)
+    feats = syn.make_pyramid(cfg, seed)
+    lss, radar = syn.make_bev(cfg, seed, 0), syn.make_bev(cfg, seed, 1)
+    metas = syn.make_img_metas(cfg)
+    t0 = time.time()
+    with torch.no_grad(), ViewTap(ref, cfg.num_cams) as tap:
+        cls, box = tr(qb, qf, feats, lss, radar, None, metas)
+    dt = time.time() - t0
+    for h in hs:
+        h.remove()
+    out = dict(cls=cls, box=box, seed=np.array(seed), weight_seed=np.array(weight_seed), ref_cpu_seconds=np.array(dt),
+               views=torch.stack(tap.views))                                  # [layers, S, Q, P] uint8
+    if mode == "tf":
+        Q = cfg.num_query
+        pq = np.linspace(0, Q - 1, TF_PROBE).round().astype(np.int64)
+        ps = pq[:: TF_PROBE // TF_PROBE_S]
+        out.update(in_bbox=torch.stack([a for a, _ in layer_in]), in_feat=torch.stack([b for _, b in layer_in]),
+                   out_feat_last=layer_out[-1][0],       # (layer l's output features are in_feat[l + 1] for l < last)
+                   out_cls=torch.stack([o[1] for o in layer_out]),
+                   out_box=torch.stack([o[2] for o in layer_out]), probe_q=pq, probe_q_sampling=ps,
+                   uv=torch.stack(tap.uv)[:, :, pq])                          # [layers, S, probe, P, 2]
+        for s, lst in stage_out.items():
+            sel = ps if s == "sampling" else pq
+            out["stage_" + s] = torch.stack([t[:, sel] for t in lst])         # [layers, B, probe, ...]
+    return out, dt
+
+
+# ------------------------------------------------------------------------------------------------ decode / head
+POST_RANGE = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
+
+
+def _decode_case(ref, cls, box, max_num, score_threshold):
+    """Reference NMSFreeCoder.decode_single and, through RaCFormer_head.get_bboxes, the z shift to the box bottom."""
+    coder = ref.nms_free_coder.NMSFreeCoder(pc_range=list(syn.PC_RANGE), post_center_range=POST_RANGE, max_num=max_num,
+                                            score_threshold=score_threshold, num_classes=cls.shape[1])
+    single = coder.decode_single(cls.clone(), box.clone())
+    import types
+    fake_head = types.SimpleNamespace(bbox_coder=coder)
+    preds = dict(all_cls_scores=cls.clone()[None, None], all_bbox_preds=box.clone()[None, None])
+    boxes, scores, labels = ref.racformer_head.RaCFormer_head.get_bboxes(fake_head, preds, None)[0]
+    return dict(bboxes=single["bboxes"], scores=single["scores"], labels=single["labels"], get_bboxes=boxes.tensor,
+                get_scores=scores, get_labels=labels)
+
+
+def gen_decode(ref):
+    """Inputs are laid out as the head emits them: cls logits [Q,C]; boxes [Q,10] = (cx, cy, w, l, cz, h, sin, cos, vx, vy)
+    with metric centres and log sizes."""
+    out = {}
+    rng = np.random.default_rng(31)
+
+    def boxes(Q):
+        b = rng.standard_normal((Q, 10), dtype=np.float32)
+        b[:, 0:2] = rng.uniform(-55, 55, (Q, 2)).astype(np.float32)
+        b[:, 4] = rng.uniform(-4, 2, Q).astype(np.float32)
+        b[:, 2:4] *= 0.3
+        b[:, 5] *= 0.3
+        return b
+
+    # --- case A: crafted, Q=40, K=12.  Exact logit ties inside the top-K, a tie group that straddles rank K (all its
+    # members in range), centres outside / exactly on post_center_range, scores just above / below the 0.05 threshold
+    Q, C, K = 40, 10, 12
+    cls = (rng.standard_normal((Q, C), dtype=np.float32) * 0.5 - 6.0)
+    box = boxes(Q)
+    thr = float(np.log(0.05 / 0.95))
+    top = [(0, 3, 4.0), (1, 7, 3.5), (2, 2, 3.5), (3, 9, 3.5), (4, 0, 2.0), (5, 5, 1.0), (6, 1, 0.5),
+           (7, 4, thr + 2e-3), (8, 6, thr + 1e-3), (9, 8, thr + 5e-4)]            # 10 ranks; three-way tie at 3.5
+    for q, c, v in top:
+        cls[q, c] = v
+    for q, c in ((10, 2), (11, 3), (12, 4), (13, 5)):                              # four-way tie across rank K = 12
+        cls[q, c] = thr - 1e-3                                                     # (below the threshold: masked anyway)
+    box[4, 0] = 70.0                       # x outside  -> masked
+    box[5, 4] = -12.0                      # z outside  -> masked
+    box[6, 0:2] = (61.2, -61.2)            # exactly on the limits -> kept (>=, <=)
+    out.update({"A_cls": cls, "A_box": box, "A_K": np.array(K)})
+    for tag, st in (("thr", 0.05), ("none", None), ("zero", 0.0)):                # 0.0: truthiness quirk of :66 (mask not applied)
+        for k, v in _decode_case(ref, torch.from_numpy(cls), torch.from_numpy(box), K, st).items():
+            out[f"A_{tag}_{k}"] = v
+
+    # --- case B: Q=900, K=300, logits quantised to 1/8 (many exact ties inside the top-K), saturated sigmoids (logit > 17
+    # all give 1.0f), 6 % of the centres outside the range.  The rank-K boundary itself is kept clean (strictly more
+    # than the next value) so that only the order inside tie groups is implementation-defined.
+    Q, C, K = 900, 10, 300
+    cls = np.round((rng.standard_normal((Q, C)) * 1.6 - 3.2) * 8) / 8
+    cls = cls.astype(np.float32)
+    for i, v in enumerate((18.0, 19.5, 25.0, 40.0)):
+        cls[17 * i + 3, (3 * i) % C] = v
+    flat = np.sort(cls.reshape(-1))[::-1]
+    kth, nxt = flat[K - 1], flat[K]
+    if kth == nxt:                                                                 # lift part of the boundary group
+        idx = np.argwhere(cls == kth)
+        n_above = int((cls > kth).sum())
+        for (q, c) in idx[: K - n_above]:
+            cls[q, c] = kth + np.float32(1.0 / 16)
+        assert np.sort(cls.reshape(-1))[::-1][K - 1] > np.sort(cls.reshape(-1))[::-1][K]
+    box = boxes(Q)
+    far = rng.random(Q) < 0.06
+    box[far, 0] = rng.uniform(62, 80, int(far.sum())).astype(np.float32)
+    out.update({"B_cls": cls, "B_box": box, "B_K": np.array(K)})
+    for k, v in _decode_case(ref, torch.from_numpy(cls), torch.from_numpy(box), K, 0.05).items():
+        out[f"B_thr_{k}"] = v
+
+    # --- case C: the benchmark's regime -- smooth random logits without ties, Q=900, K=300
+    cls = (rng.standard_normal((Q, C), dtype=np.float32) * 1.2 - 2.5)
+    box = boxes(Q)
+    out.update({"C_cls": cls, "C_box": box, "C_K": np.array(K)})
+    for k, v in _decode_case(ref, torch.from_numpy(cls), torch.from_numpy(box), K, 0.05).items():
+        out[f"C_thr_{k}"] = v
+    save("decode_cases.npz", **out)
+
+
+def run_head(ref, cfg, seed, weight_seed):
+    """RaCFormer_head (inference): _init_layers as the reference runs it, then seeded weights, forward, get_bboxes."""
+    torch.manual_seed(1234)
+    head = ref.racformer_head.RaCFormer_head(
+        num_classes=cfg.num_classes, in_channels=cfg.embed_dims, num_query=cfg.num_query, num_clusters=cfg.num_clusters,
+        code_size=cfg.code_size, query_denoising=True, query_denoising_groups=10,
+        transformer=dict(type="RaCFormerTransformer", **cfg.transformer_kwargs()),
+        bbox_coder=dict(type="NMSFreeCoder", post_center_range=POST_RANGE, pc_range=list(cfg.pc_range), max_num=300,
+                        score_threshold=0.05, num_classes=cfg.num_classes)).eval()
+    init_q = head.init_query_bbox.weight.detach().clone()          # columns 0,1,2,5,8,9 are deterministic (:55-63)
+    gen_pts = head.generate_points().clone()
+    syn.fill_params(head.transformer, weight_seed)
+    with torch.no_grad():
+        head.label_enc.weight.copy_(torch.from_numpy(syn.rng_normal(77 + seed, tuple(head.label_enc.weight.shape), 0.1)))
+        head.init_query_bbox.weight.copy_(syn.make_queries(cfg, seed)[0][0])
+    feats = syn.make_pyramid(cfg, seed)
+    lss, radar = syn.make_bev(cfg, seed, 0), syn.make_bev(cfg, seed, 1)
+    t0 = time.time()
+    with torch.no_grad(), ViewTap(ref, cfg.num_cams) as tap:
+        preds = head(feats, lss, radar, syn.make_img_metas(cfg))
+        cls, box = preds["all_cls_scores"].clone(), preds["all_bbox_preds"].clone()
+        boxes, scores, labels = head.get_bboxes(preds, syn.make_img_metas(cfg))[0]
+    dt = time.time() - t0
+    assert preds["enc_cls_scores"] is None and "dn_mask_dict" not in preds
+    return dict(seed=np.array(seed), weight_seed=np.array(weight_seed), init_query_cols=np.array([0, 1, 2, 5, 8, 9]),
+                init_query_fixed=init_q[:, [0, 1, 2, 5, 8, 9]], generate_points=gen_pts,
+                label_enc=head.label_enc.weight.detach().clone(), all_cls_scores=cls, all_bbox_preds=box,
+                det_boxes=boxes.tensor, det_scores=scores, det_labels=labels, views=torch.stack(tap.views),
+                ref_cpu_seconds=np.array(dt)), dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-f8", action="store_true")
@@ -236,6 +427,7 @@ def main():
     ref = ref_loader.load_reference()
     ref.utils_bbox = sys.modules["models.bbox.utils"]
     ref.utils = sys.modules["models.utils"]
+    ref.nms_free_coder = sys.modules["models.bbox.coders.nms_free_coder"]
 
     def want(k):
         return not args.only or k in args.only.split(",")
@@ -264,6 +456,26 @@ def main():
         out, dt = run_decoder(ref, syn.F8_3CAM, seed=0, weight_seed=0, full_stages=False)
         print(f"  decoder F8 3-cam ref forward {dt:.2f}s")
         save("decoder_f8_3cam.npz", **out)
+    if want("decode"):
+        gen_decode(ref)
+    if want("head"):
+        out, dt = run_head(ref, syn.SMALL6, seed=9, weight_seed=10)
+        save("head_small6.npz", **out)
+        if not args.skip_f8:
+            out, dt = run_head(ref, syn.F8, seed=4, weight_seed=4)
+            print(f"  head F8 ref forward {dt:.2f}s")
+            save("head_f8.npz", **out)
+    if not args.skip_f8 and want("seeds"):
+        for sd_ in (1, 2, 3):
+            out, dt = run_decoder(ref, syn.F8, seed=sd_, weight_seed=sd_, full_stages=False, mode="seeds")
+            print(f"  decoder F8 seed {sd_} ref forward {dt:.2f}s")
+            save(f"decoder_f8_s{sd_}.npz", **out)
+        out, dt = run_decoder(ref, syn.F8_3CAM, seed=1, weight_seed=1, full_stages=False, mode="seeds")
+        save("decoder_f8_3cam_s1.npz", **out)
+    if not args.skip_f8 and want("tf"):
+        out, dt = run_decoder(ref, syn.F8, seed=0, weight_seed=0, full_stages=False, mode="tf")
+        print(f"  decoder F8 teacher-forcing fixture {dt:.2f}s")
+        save("decoder_f8_tf.npz", **out)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ imports it.
 
 The reference's ``models/__init__.py`` pulls mmdet / mmdet3d / flash_attn, which are
 not installed.  We therefore register empty namespace packages whose ``__path__``
-points into ``/root/reference/models`` and load the eight hot-path files one by one
+points into ``/root/reference/models`` and load the ten hot-path files one by one
 (recipe: SURVEY.md Appendix C).  The handful of mmcv / mmdet names those files
 import are stubbed below from the documented behaviour of mmcv-full 1.6.0 and
 mmdet 2.28.2 (``README.md:44-45`` of the reference); each stub sits on a torch
@@ -187,10 +187,59 @@ def _msda_pytorch(value, value_spatial_shapes, sampling_locations, attention_wei
 
 
 class _Registry:
+    """mmcv Registry, plumbing only: remembers the decorated classes by name so that a config's
+    ``type`` can be resolved (``build``); no behaviour of its own."""
+
+    def __init__(self):
+        self.classes = {}
+
     def register_module(self, *a, **k):
         def deco(cls):
+            self.classes[cls.__name__] = cls
             return cls
         return deco
+
+    def build(self, cfg):
+        cfg = dict(cfg)
+        return self.classes[cfg.pop("type")](**cfg)
+
+
+class _BaseBBoxCoder:
+    """mmdet.core.bbox.BaseBBoxCoder (2.28.2): an abstract base without arithmetic."""
+
+    def __init__(self, **kwargs):
+        pass
+
+
+class _LiDARInstance3DBoxes:
+    """mmdet3d LiDARInstance3DBoxes as used by get_bboxes (racformer_head.py:503): a holder of the
+    [n, box_dim] tensor; none of its geometry helpers are on the path."""
+
+    def __init__(self, tensor, box_dim=7, with_yaw=True, origin=(0.5, 0.5, 0)):
+        assert tuple(origin) == (0.5, 0.5, 0), "only the default (bottom-centre) origin is stubbed"
+        self.tensor = tensor
+        self.box_dim = box_dim
+
+
+_TRANSFORMER, _BBOX_CODERS, _HEADS = _Registry(), _Registry(), _Registry()
+
+
+class _DETRHead(_BaseModule):
+    """mmdet 2.28.2 DETRHead.__init__ reduced to its plumbing: remember the constructor arguments the
+    subclass reads, build ``transformer`` from its config through the TRANSFORMER registry, call the
+    subclass' ``_init_layers``.  The losses / assigner / sine positional encoding it also builds are
+    training-only or unused by RaCFormer_head.forward and are not instantiated."""
+
+    def __init__(self, num_classes, in_channels, num_query=100, num_reg_fcs=2, transformer=None,
+                 sync_cls_avg_factor=False, positional_encoding=None, loss_cls=None, loss_bbox=None,
+                 loss_iou=None, train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        self.num_query, self.num_classes, self.in_channels = num_query, num_classes, in_channels
+        self.num_reg_fcs, self.train_cfg, self.test_cfg = num_reg_fcs, train_cfg, test_cfg
+        self.fp16_enabled = False
+        self.transformer = _TRANSFORMER.build(transformer)
+        self.embed_dims = self.transformer.embed_dims
+        self._init_layers()
 
 
 def _mod(name, **attrs):
@@ -218,7 +267,19 @@ def _install_stubs():
     _mod("mmdet")
     _mod("mmdet.models")
     _mod("mmdet.models.utils")
-    _mod("mmdet.models.utils.builder", TRANSFORMER=_Registry())
+    _mod("mmdet.models.utils.builder", TRANSFORMER=_TRANSFORMER)
+    # decode / head end of the path (models/bbox/coders/nms_free_coder.py:3-4, models/racformer_head.py:4-9)
+    _mod("mmdet.core", multi_apply=None, reduce_mean=None)       # training-only helpers, never called here
+    _mod("mmdet.core.bbox", BaseBBoxCoder=_BaseBBoxCoder)
+    _mod("mmdet.core.bbox.builder", BBOX_CODERS=_BBOX_CODERS)
+    sys.modules["mmdet.models"].HEADS = _HEADS
+    _mod("mmdet.models.dense_heads", DETRHead=_DETRHead)
+    _mod("mmdet3d")
+    _mod("mmdet3d.core")
+    _mod("mmdet3d.core.bbox")
+    _mod("mmdet3d.core.bbox.coders", build_bbox_coder=_BBOX_CODERS.build)
+    _mod("mmdet3d.core.bbox.structures")
+    _mod("mmdet3d.core.bbox.structures.lidar_box3d", LiDARInstance3DBoxes=_LiDARInstance3DBoxes)
 
 
 _FILES = [
@@ -230,6 +291,8 @@ _FILES = [
     ("models.multi_scale_deformable_attn_function", "models/multi_scale_deformable_attn_function.py"),
     ("models.bev_self_attention", "models/bev_self_attention.py"),
     ("models.racformer_transformer", "models/racformer_transformer.py"),
+    ("models.bbox.coders.nms_free_coder", "models/bbox/coders/nms_free_coder.py"),
+    ("models.racformer_head", "models/racformer_head.py"),
 ]
 
 
@@ -240,7 +303,7 @@ def load_reference():
                            "generated in the build container")
     _install_stubs()
     for pkg, sub in (("models", "models"), ("models.bbox", "models/bbox"),
-                     ("models.csrc", "models/csrc")):
+                     ("models.csrc", "models/csrc"), ("models.bbox.coders", "models/bbox/coders")):
         if pkg not in sys.modules:
             m = types.ModuleType(pkg)
             m.__path__ = [os.path.join(REF_ROOT, sub)]

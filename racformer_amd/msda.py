@@ -9,9 +9,22 @@ import torch
 from . import _lib
 
 
+_host_cache = {}   # (data_ptr, version, numel, device) of a shape tensor -> (tensor kept alive, host copy)
+
+
 def _host_i64(x):
+    """spatial_shapes / level_start_index as a host int64 array.  The reference passes device tensors
+    (bev_self_attention.py:189-201); reading one back synchronises the host with the stream, so the copy is made once per
+    tensor (identity + in-place version; the entry holds the tensor, so its address cannot be reused) and every later call
+    with that tensor is sync-free."""
     if isinstance(x, torch.Tensor):
-        x = x.detach().cpu().reshape(-1).tolist()  # tiny D2H; callers on the hot path pass lists
+        key = (x.data_ptr(), x._version, x.numel(), str(x.device))
+        hit = _host_cache.get(key)
+        if hit is None:
+            if len(_host_cache) >= 64:
+                _host_cache.clear()
+            hit = _host_cache[key] = (x, x.detach().cpu().reshape(-1).tolist())
+        x = hit[1]
     else:
         x = [int(v) for row in x for v in (row if isinstance(row, (list, tuple)) else [row])]
     return (ctypes.c_int64 * len(x))(*[int(v) for v in x]), len(x)

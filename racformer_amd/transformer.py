@@ -178,6 +178,9 @@ class RaCFormerSampling(nn.Module):
         self.ray_points_offset = nn.Linear(embed_dims, depth_num)
         self.sampling_offset = nn.Linear(embed_dims, depth_num * num_groups * num_points * 3)
         self.scale_weights = nn.Linear(embed_dims, num_groups * num_frames * depth_num * num_points * num_levels)
+        # a list: every call appends the (u, v, view / (N-1)) locations it sampled at, [S,Q,P,3] -- the kernel's own loc_out on
+        # the fused path; the reference's DUMP hook (sparsebev_sampling.py:82-87).  Parity tests use them to show view flips.
+        self.capture_loc = None
 
     def init_weights(self):
         bias = self.sampling_offset.bias.data.view(self.depth_num * self.num_groups * self.num_points, 3)
@@ -208,7 +211,7 @@ class RaCFormerSampling(nn.Module):
         """torch keypoint chain + sampling_4d on the msmv operator (the reference's decomposition)."""
         image_h, image_w, _ = img_metas[0]["img_shape"][0]
         points, sw = self.keypoints(query_ray, query_feat, img_metas[0]["time_diff"], d_region)
-        return sampling_4d(points, mlvl_feats, sw, img_metas[0]["lidar2img"], image_h, image_w)
+        return sampling_4d(points, mlvl_feats, sw, img_metas[0]["lidar2img"], image_h, image_w, loc_tap=self.capture_loc)
 
     def forward(self, query_ray, query_feat, mlvl_feats, img_metas, d_region=0.1, linear_out=None, debug=False,
                 box_table=None):
@@ -219,14 +222,18 @@ class RaCFormerSampling(nn.Module):
             linear_out = (self.sampling_offset(query_feat), self.ray_points_offset(query_feat),
                           self.scale_weights(query_feat))
         off, ray, sc = linear_out
-        return sampling4d_fused(mlvl_feats, query_ray.contiguous(), off, ray, sc, img_metas[0]["time_diff"],
-                                img_metas[0]["lidar2img"], self.num_frames, self.num_groups, self.num_points,
-                                self.depth_num, self.pc_range, d_region, image_h, image_w, debug=debug,
-                                box_table=box_table)
+        res = sampling4d_fused(mlvl_feats, query_ray.contiguous(), off, ray, sc, img_metas[0]["time_diff"],
+                               img_metas[0]["lidar2img"], self.num_frames, self.num_groups, self.num_points,
+                               self.depth_num, self.pc_range, d_region, image_h, image_w,
+                               debug=debug or self.capture_loc is not None, box_table=box_table)
+        if self.capture_loc is not None:
+            self.capture_loc.append(res[1])
+            return res if debug else res[0]
+        return res
 
 
 def sampling_4d(sample_points, mlvl_feats, scale_weights, lidar2img, image_h, image_w, aggregate=True,
-                eps=1e-5):
+                eps=1e-5, loc_tap=None):
     """sparsebev_sampling.py:28-134 on the HIP msmv operator.
     sample_points [B,Q,T,G,P,3]; mlvl_feats[l] [B*T*G,N,H,W,C] channel-last; scale_weights
     [B,Q,G,T,P,L]; lidar2img [B,T*N,4,4] -> [B,Q,G,T*P,C].  Projection, validity, first-valid-view
@@ -250,6 +257,8 @@ def sampling_4d(sample_points, mlvl_feats, scale_weights, lidar2img, image_h, im
     v_sel = torch.gather(v, 2, i_view)[:, :, 0]                                      # [B,T,Q,GP]
     loc = torch.stack([u_sel, v_sel, i_view[:, :, 0].to(u.dtype) / (N - 1)], dim=-1)
     loc = loc.view(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * T * G, Q, P, 3).contiguous()
+    if loc_tap is not None:
+        loc_tap.append(loc)
     L = scale_weights.shape[-1]
     w = scale_weights.reshape(B, Q, G, T, P, L).permute(0, 2, 3, 1, 4, 5).reshape(B * G * T, Q, P, L).contiguous()
     return msmv_forward(mlvl_feats, loc, w, out_layout=_lib.OUT_BQGTPC, num_frames=T, num_groups=G)
@@ -838,7 +847,6 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # radar stream: value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack)
         self.compose_radar_value = True
         self._pack_cache = {}
-        self.capture_loc = None   # a list: every layer appends the sampling kernel's own locations (see _sample)
 
     def _cached(self, key, params, fn):
         """Weight-derived operands (concatenations, re-layouts, f16 splits) are functions of the parameters only:
@@ -862,21 +870,36 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         nn.init.xavier_uniform_(self.fusion.weight)
         nn.init.constant_(self.fusion.bias, 0.0)
 
+    def mfma_report(self, cfg, split):
+        """(timer key, kernel description, algorithmic flops, executed flops, peak class 16 | 32) of the dense contractions
+        of one forward that run on the matrix cores -- what bench.py prices against the gfx950 MFMA peaks."""
+        Qn, E, G_, C_ = cfg.num_query, cfg.embed_dims, cfg.num_groups, cfg.channels
+        Pin = cfg.num_points * cfg.num_frames * cfg.img_depth_num
+        gen_cols = G_ * (C_ * C_ + 128 * Pin)
+        bev_h, bev_w = cfg.bev_hw
+        conv = 2.0 * cfg.num_frames * bev_h * bev_w * 256 * 320 * 9
+        return [
+            ("mixing_fwd", "mixing_c64_f16x3_kernel (hand-written; x@M: 6 bf16 products, S@Y: 3 f16 products)" if split
+             else "mixing_c64_kernel (hand-written, v_mfma_f32_16x16x4_f32)",
+             2.0 * Qn * G_ * (Pin * C_ * C_ + 128 * Pin * C_),
+             2.0 * Qn * G_ * (6 * 96 * C_ * C_ + 3 * 128 * 96 * C_) if split else 2.0 * Qn * G_ * (96 * C_ * C_ + 128 * 96 * C_),
+             16 if split else 32),
+            ("mixing_generator_gemm", "parameter_generator GEMM (hipBLASLt f16, K-concatenated hi/lo operands)" if split
+             else "parameter_generator GEMM (rocBLAS fp32)",
+             2.0 * Qn * E * gen_cols, 2.0 * Qn * gen_cols * ((3 * E + 64) if split else E), 16 if split else 32),
+            ("mixing_out_proj_gemm", "out_proj split-K batched GEMM (hipBLASLt f16, K-concatenated hi/lo operands)" if split
+             else "out_proj split-K batched GEMM (rocBLAS fp32)",
+             2.0 * Qn * (G_ * 128 * C_) * E, 2.0 * Qn * (G_ * 128 * C_) * E * (3 if split else 1), 16 if split else 32),
+            ("temporal_fusion_conv", "conv3x3_f16x3_kernel (hand-written implicit GEMM, 3 f16 products; value_proj composed in)",
+             conv, 3 * conv, 16)]
+
     def refine_bbox(self, bbox_proposal, bbox_delta):
         dz_new = torch.sigmoid(bbox_delta[..., 1:3] + inverse_sigmoid(bbox_proposal[..., 1:3]))
         theta = bbox_proposal[..., 0:1] + (torch.sigmoid(bbox_delta[..., 0:1]) * 2 - 1) / self.num_ray
         return torch.cat([theta, dz_new, bbox_delta[..., 3:]], dim=-1)
 
     def _sample(self, qb, x1, mlvl_feats, img_metas, d_region, linear_out, table):
-        """The fused sampling launch; with ``capture_loc`` set to a list, the kernel also writes the locations it sampled at
-        ((u, v, view / (N-1)) per point, [S,Q,P,3] -- the reference's DUMP hook, sparsebev_sampling.py:82-87) and they are
-        appended to it: the parity tests use them to attribute first-valid-view flips."""
-        if self.capture_loc is None:
-            return self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=linear_out, box_table=table)
-        out, loc, _ = self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=linear_out, box_table=table,
-                                    debug=True)
-        self.capture_loc.append(loc)
-        return out
+        return self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=linear_out, box_table=table)
 
     def _side_stream(self, device):
         if getattr(self, "_side", None) is None or self._side.device != device:

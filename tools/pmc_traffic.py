@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc runs: per-kernel average FETCH_SIZE / WRITE_SIZE (separate passes, as
 MI355X_MICROARCH.md prescribes) -> profiles/<tag>_pmc_traffic.json.
-usage: pmc_traffic.py <tag> <dir_with_fetch_pass> <dir_with_write_pass>"""
-import csv, glob, json, os, sys
+usage: pmc_traffic.py <tag> <dir_with_fetch_pass> <dir_with_write_pass>      (tag ends in the bench config: r02_pmc_traffic_f8)
+The summary records the sha256 of the gather kernels' source files: bench.py reports `roofline.traffic` only from a summary
+captured from the very kernel version it is timing."""
+import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = ["racformer_amd/csrc/sampling_fused.hip", "racformer_amd/csrc/bev_fused.hip", "racformer_amd/csrc/mixing.hip"]
 
 
 def load(d, counter):
@@ -18,9 +23,10 @@ def load(d, counter):
 def main():
     tag, dfetch, dwrite = sys.argv[1:4]
     fetch, write = load(dfetch, "FETCH_SIZE"), load(dwrite, "WRITE_SIZE")
-    out = {}
+    out = {"_source_sha": {rel: hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16] for rel in SOURCES
+                           if os.path.exists(os.path.join(ROOT, rel))}}
     for k in sorted(set(fetch) | set(write)):
-        if not any(s in k for s in ("sampling4d", "bev_sampling", "msmv_fwd", "msda_fwd", "regroup", "sasa", "mixing", "conv3x3", "conv_pack", "rowgemm", "absmax")):
+        if not any(s in k for s in ("sampling4d", "bev_sampling", "msmv_fwd", "msda_fwd", "regroup", "sasa", "mixing", "conv3x3", "conv_pack", "rowgemm", "absmax", "genmix", "outproj")):
             continue
         f = fetch.get(k, [])
         w = write.get(k, [])
@@ -34,7 +40,7 @@ def main():
             "read_bytes_corrected": fk * 1024 * 2 if fk is not None else None,
             "write_bytes": wk * 1024 if wk is not None else None,
         }
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", f"{tag}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

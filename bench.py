@@ -386,7 +386,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import restate as R  # the checker, timed as the reported CPU baseline only
-        from parity import attribution, head_boxes_normalised
+        from parity import flipped_points, head_boxes_normalised
         torch.set_num_threads(host_threads())
         sd = {k: v.detach().cpu() for k, v in head.transformer.state_dict().items()}
         hsd = {k: v.detach().cpu() for k, v in head.state_dict().items() if not k.startswith("transformer.")}
@@ -413,8 +413,7 @@ def main():
         views = torch.stack([R.views_of(l.cpu(), cfg.num_cams) for l in taps])
         got_n = head_boxes_normalised(preds["all_bbox_preds"].cpu(), cfg.pc_range)
         ref_n = head_boxes_normalised(ref["all_bbox_preds"], cfg.pc_range)
-        att, nflips = attribution(views, oviews, hsd["init_query_bbox.weight"][None],
-                                  torch.stack([ref_n[..., 0], ref_n[..., 1]], dim=-1), cfg)
+        nflips = flipped_points(views, oviews)
         eb = (got_n - ref_n).abs().amax(-1)
         mism = preds["all_cls_scores"].cpu().argmax(-1) != ref["all_cls_scores"].argmax(-1)
         result["cpu_baseline"] = {
@@ -426,9 +425,11 @@ def main():
         result["parity_vs_oracle"] = {
             "space": "decoder-normalised boxes (xyz / pc_range span, log sizes, sin, cos, v)",
             "box_abs_err_median": float(eb.median()), "box_abs_err_max": float(eb.max()),
-            "queries_over_1e-3": int((eb > 1e-3).sum()), "queries_over_1e-3_not_attributed_to_a_view_flip": int(((eb > 1e-3) & ~att).sum()),
-            "argmax_mismatches": int(mism.sum()), "argmax_mismatches_not_attributed": int((mism & ~att).sum()),
-            "view_flips_per_layer": nflips}
+            "queries_over_1e-3_per_layer": (eb > 1e-3).flatten(1).sum(1).tolist(),
+            "argmax_mismatches_per_layer": mism.flatten(1).sum(1).tolist(),
+            "differing_camera_choices_per_layer": nflips,
+            "note": "free-running six layers with each side's own camera choices (tests/parity.py explains the criterion the "
+                    "tests apply: differing choices equalised, per-layer tail budget)"}
 
     if rank == 0:
         print(json.dumps(result))

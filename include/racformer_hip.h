@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RAC_ABI_VERSION 1
+#define RAC_ABI_VERSION 2
 #define RAC_MAX_LEVELS 8
 #define RAC_MAX_POINTS 128 /* same limit as the reference, msmv_sampling_forward.cu:21 */
 
@@ -116,11 +116,15 @@ int rac_box_prep_fwd(const float *query_bbox, float *table, int num_boxes, const
  *   time_diff    : device f32 [B,T];  lidar2img: device f32 [B,T*N,4,4]
  *   out          : device f32 [B,Q,G,T*NP*D,64]
  *   loc_out,w_out: optional debug outputs [S,Q,P,3] (u,v,view/(N-1)) and [S,Q,P,L] (NULL,NULL to skip)
+ *   view_in      : optional device u8 [S,Q,P]: the camera index to sample each point in, INSTEAD of the first valid view
+ *                  (sparsebev_sampling.py:97-110).  NULL on the product path; parity tests pass the reference's own
+ *                  choices to take the path's one discontinuous step out of a comparison.
  *   pc_range (6), depth_base (D = torch.linspace(-d_region,d_region,D)): HOST pointers */
 int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox,
                        const float *box_table, const float *offsets, const float *ray_logits, const float *scale_logits,
                        const float *time_diff, const float *lidar2img, float *out, float *loc_out,
-                       float *w_out, int ld_off, int ld_ray, int ld_scale, int B, int T, int N, int G, int Q,
+                       float *w_out, const unsigned char *view_in, int ld_off, int ld_ray, int ld_scale, int B, int T, int N,
+                       int G, int Q,
                        int NP, int D, int C, const float *pc_range, const float *depth_base, float d_region,
                        float image_h, float image_w, float eps, int dtype, void *stream);
 

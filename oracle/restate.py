@@ -235,6 +235,7 @@ def msda(value, shapes, starts, loc, attn, force_torch=False):
 
 # =============================================================================== sampling_4d
 LOC_TAP = None   # set to a list by a test to collect every sampling_4d call's (u, v, view / (N-1)) locations
+VIEW_FORCE = None  # a list of u8 [S,Q,P] arrays, consumed one per sampling_4d call: camera index imposed on every point
 
 
 def views_of(loc, num_cams):
@@ -242,9 +243,10 @@ def views_of(loc, num_cams):
     return torch.round(loc[..., 2] * (num_cams - 1)).to(torch.uint8)
 
 
-def project_select(points, lidar2img, image_h, image_w, eps=1e-5):
+def project_select(points, lidar2img, image_h, image_w, eps=1e-5, force_view=None):
     """models/sparsebev_sampling.py:45-110.  points [B,Q,T,GP,3]; lidar2img [B,T*N,4,4].
-    Returns loc [B,T,Q,GP,3] = (u, v, i_view/(N-1)), i_view [B,T,Q,GP], valid-any [B,T,Q,GP]."""
+    Returns loc [B,T,Q,GP,3] = (u, v, i_view/(N-1)), i_view [B,T,Q,GP], valid-any [B,T,Q,GP].
+    ``force_view`` [B,T,Q,GP] (tests): take this camera for every point instead of the first valid one."""
     B, Q, T, GP, _ = points.shape
     N = lidar2img.shape[1] // T
     m = lidar2img.reshape(B, T, N, 1, 1, 4, 4)
@@ -258,6 +260,8 @@ def project_select(points, lidar2img, image_h, image_w, eps=1e-5):
     valid = (homo > eps) & (v > 0.0) & (v < 1.0) & (u > 0.0) & (u < 1.0)   # [B,T,N,Q,GP]
     validf = valid.float().permute(0, 1, 3, 4, 2)              # [B,T,Q,GP,N]
     i_view = torch.argmax(validf, dim=-1)                      # first valid, 0 if none
+    if force_view is not None:
+        i_view = force_view.long()
     idx = i_view[..., None]
     u_sel = torch.gather(u.permute(0, 1, 3, 4, 2), -1, idx)[..., 0]
     v_sel = torch.gather(v.permute(0, 1, 3, 4, 2), -1, idx)[..., 0]
@@ -271,8 +275,11 @@ def sampling_4d(sample_points, feats_cl, scale_weights, lidar2img, image_h, imag
     Slot order of points/features/outputs is (b,t,g); the weights are flattened (b,g,t)
     (:118-120) and consumed slot-by-slot as they lie -- reproduced as written (quirk Q1)."""
     B, Q, T, G, P, _ = sample_points.shape
+    force = None
+    if VIEW_FORCE:
+        force = torch.as_tensor(np.asarray(VIEW_FORCE.pop(0))).view(B, T, G, Q, P).permute(0, 1, 3, 2, 4).reshape(B, T, Q, G * P)
     loc, _, _ = project_select(sample_points.reshape(B, Q, T, G * P, 3), lidar2img, image_h,
-                               image_w, eps)
+                               image_w, eps, force)
     loc = loc.reshape(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * T * G, Q, P, 3)
     if LOC_TAP is not None:           # tests: the locations handed to the msmv op, one [S,Q,P,3] tensor per call
         LOC_TAP.append(loc.clone())

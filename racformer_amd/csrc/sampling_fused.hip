@@ -23,7 +23,6 @@
 // slot s are read from the (b,g',t') flattening at s' = t*G+g, g' = s'/T, t' = s'%T
 // (sparsebev_sampling.py:113-120, quirk Q1).
 #include "rac_common.h"
-#include <stdlib.h>
 
 #ifndef S4D_ROWS
 #define S4D_ROWS 16 /* queries per workgroup: one prologue pass (up to 192 keypoints on 192 threads) serves 4 gather rounds */
@@ -51,6 +50,7 @@ struct S4dArgs {
     float *out;              // [B,Q,G,T*P,C]
     float *loc_out;          // optional [S,Q,P,3]
     float *w_out;            // optional [S,Q,P,L]
+    const unsigned char *view_in;  // optional [S,Q,P]: camera index to use instead of the first valid one (parity tests)
     float depth_base[S4D_MAX_DEPTH];
     float pc[6];
     float d_region, image_h, image_w, eps;
@@ -97,6 +97,9 @@ __device__ __forceinline__ void s4d_keypoint(const S4dArgs &a, const float *sl2i
     float u_sel = 0.f, v_sel = 0.f;
     int view = 0;
     bool found = false;
+    // view_in imposes the camera choice (the one discontinuous step of the path) from outside: with the reference's
+    // own choices the whole decoder is a continuous function of its inputs, which is what the parity tests compare
+    const int forced = a.view_in ? (int)a.view_in[((((size_t)b * a.T + t) * a.G + g) * a.Q + q) * a.P + p] : -1;
     for (int n = 0; n < a.N; ++n) {
         const float *m = sl2i + n * 16;
         const float camx = m[0] * X + m[1] * Y + m[2] * pz + m[3];
@@ -106,7 +109,7 @@ __device__ __forceinline__ void s4d_keypoint(const S4dArgs &a, const float *sl2i
         const float u = camx / hz / a.image_w;
         const float v = camy / hz / a.image_h;
         const bool valid = homo > a.eps && v > 0.f && v < 1.f && u > 0.f && u < 1.f;
-        if (n == 0 || (valid && !found)) {
+        if (forced >= 0 ? n == forced : (n == 0 || (valid && !found))) {
             u_sel = u;
             v_sel = v;
             view = n;
@@ -253,7 +256,7 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
                                   const float *box_table,
                                   const float *offsets, const float *ray_logits, const float *scale_logits,
                                   const float *time_diff, const float *lidar2img, float *out, float *loc_out,
-                                  float *w_out, int ld_off, int ld_ray, int ld_scale, int B, int T, int N, int G, int Q, int NP,
+                                  float *w_out, const unsigned char *view_in, int ld_off, int ld_ray, int ld_scale, int B, int T, int N, int G, int Q, int NP,
                                   int D, int C,
                                   const float *pc_range, const float *depth_base, float d_region, float image_h,
                                   float image_w, float eps, int dtype, void *stream)
@@ -286,7 +289,7 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
         a.W[l] = hw[2 * l + 1];
     }
     a.qbox = query_bbox; a.box = box_table; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
-    a.time_diff = time_diff; a.l2i = lidar2img; a.out = out; a.loc_out = loc_out; a.w_out = w_out;
+    a.time_diff = time_diff; a.l2i = lidar2img; a.out = out; a.loc_out = loc_out; a.w_out = w_out; a.view_in = view_in;
     for (int i = 0; i < S4D_MAX_DEPTH; ++i)
         a.depth_base[i] = i < D ? depth_base[i] : 0.f;
     for (int i = 0; i < 6; ++i)
@@ -294,8 +297,7 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
     a.d_region = d_region; a.image_h = image_h; a.image_w = image_w; a.eps = eps;
     a.L = L; a.B = B; a.T = T; a.N = N; a.G = G; a.Q = Q; a.NP = NP; a.D = D; a.P = P;
     a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale;
-    static const int rows_env = getenv("RAC_S4D_ROWS") ? atoi(getenv("RAC_S4D_ROWS")) : 0;
-    a.rows = rows_env >= 4 && rows_env <= 64 && rows_env % 4 == 0 ? rows_env : S4D_ROWS;
+    a.rows = S4D_ROWS;
     a.blocks_per_slot = (Q + a.rows - 1) / a.rows;
     const int S = B * T * G;
     const int nb = 8 * ((S + 7) / 8) * a.blocks_per_slot;

@@ -39,9 +39,10 @@ def box_prep(query_bbox, pc_range):
 
 def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, time_diff, lidar2img,
                      num_frames, num_groups, num_points, depth_num, pc_range, d_region, image_h, image_w,
-                     eps=1e-5, debug=False, box_table=None):
+                     eps=1e-5, debug=False, box_table=None, view_in=None):
     """-> [B,Q,G,T*P,C] (and, with debug=True, the kernel's own locations [S,Q,P,3] and softmaxed scale
-    weights [S,Q,P,L] for parity checks)."""
+    weights [S,Q,P,L] for parity checks).  ``view_in`` (u8 [S,Q,P], parity tests only): camera index per point that
+    replaces the kernel's own first-valid-view selection."""
     feats = list(mlvl_feats)
     L = len(feats)
     _lib.require_gpu(*feats, query_bbox, time_diff, lidar2img, what="sampling4d_fused")
@@ -63,6 +64,11 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
     if debug:
         loc_out = torch.empty(S, Q, P, 3, device=out.device, dtype=torch.float32)
         w_out = torch.empty(S, Q, P, L, device=out.device, dtype=torch.float32)
+    if view_in is not None:
+        if view_in.dtype != torch.uint8 or tuple(view_in.shape) != (S, Q, P) or not view_in.is_cuda or not view_in.is_contiguous():
+            raise RuntimeError(f"sampling4d_fused: view_in must be a contiguous CUDA uint8 [{S},{Q},{P}] tensor")
+        if int(view_in.max()) >= N:
+            raise RuntimeError("sampling4d_fused: view_in holds a camera index >= N")
     ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
     hw = (ctypes.c_int32 * (2 * L))(*[int(x) for f in feats for x in f.shape[2:4]])
     pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
@@ -72,7 +78,7 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
     rc = _lib.lib().rac_sampling4d_fwd(
         ptrs, hw, L, _lib.ptr(query_bbox), _lib.ptr(box_table), p_off, p_ray, p_sc, _lib.ptr(time_diff), _lib.ptr(lidar2img),
         _lib.ptr(out), _lib.ptr(loc_out) if debug else None, _lib.ptr(w_out) if debug else None,
-        ld_off, ld_ray, ld_sc, B, T, N, G, Q, NP, D, C, pc, _depth_base(float(d_region), D), float(d_region),
+        _lib.ptr(view_in) if view_in is not None else None, ld_off, ld_ray, ld_sc, B, T, N, G, Q, NP, D, C, pc, _depth_base(float(d_region), D), float(d_region),
         float(image_h), float(image_w), float(eps), _lib.dtype_code(feats[0]), _lib.stream_ptr())
     if ev:
         ev[1].record()

@@ -181,6 +181,12 @@ class RaCFormerSampling(nn.Module):
         # a list: every call appends the (u, v, view / (N-1)) locations it sampled at, [S,Q,P,3] -- the kernel's own loc_out on
         # the fused path; the reference's DUMP hook (sparsebev_sampling.py:82-87).  Parity tests use them to show view flips.
         self.capture_loc = None
+        # a list of u8 [S,Q,P] tensors, consumed one per call: the camera index every point is to be sampled in, replacing
+        # the first-valid-view selection (parity tests impose the reference's own choices: tests/parity.py)
+        self.force_views = None
+
+    def _next_forced(self):
+        return self.force_views.pop(0) if self.force_views else None
 
     def init_weights(self):
         bias = self.sampling_offset.bias.data.view(self.depth_num * self.num_groups * self.num_points, 3)
@@ -211,7 +217,8 @@ class RaCFormerSampling(nn.Module):
         """torch keypoint chain + sampling_4d on the msmv operator (the reference's decomposition)."""
         image_h, image_w, _ = img_metas[0]["img_shape"][0]
         points, sw = self.keypoints(query_ray, query_feat, img_metas[0]["time_diff"], d_region)
-        return sampling_4d(points, mlvl_feats, sw, img_metas[0]["lidar2img"], image_h, image_w, loc_tap=self.capture_loc)
+        return sampling_4d(points, mlvl_feats, sw, img_metas[0]["lidar2img"], image_h, image_w, loc_tap=self.capture_loc,
+                           view_in=self._next_forced())
 
     def forward(self, query_ray, query_feat, mlvl_feats, img_metas, d_region=0.1, linear_out=None, debug=False,
                 box_table=None):
@@ -225,7 +232,7 @@ class RaCFormerSampling(nn.Module):
         res = sampling4d_fused(mlvl_feats, query_ray.contiguous(), off, ray, sc, img_metas[0]["time_diff"],
                                img_metas[0]["lidar2img"], self.num_frames, self.num_groups, self.num_points,
                                self.depth_num, self.pc_range, d_region, image_h, image_w,
-                               debug=debug or self.capture_loc is not None, box_table=box_table)
+                               debug=debug or self.capture_loc is not None, box_table=box_table, view_in=self._next_forced())
         if self.capture_loc is not None:
             self.capture_loc.append(res[1])
             return res if debug else res[0]
@@ -233,7 +240,7 @@ class RaCFormerSampling(nn.Module):
 
 
 def sampling_4d(sample_points, mlvl_feats, scale_weights, lidar2img, image_h, image_w, aggregate=True,
-                eps=1e-5, loc_tap=None):
+                eps=1e-5, loc_tap=None, view_in=None):
     """sparsebev_sampling.py:28-134 on the HIP msmv operator.
     sample_points [B,Q,T,G,P,3]; mlvl_feats[l] [B*T*G,N,H,W,C] channel-last; scale_weights
     [B,Q,G,T,P,L]; lidar2img [B,T*N,4,4] -> [B,Q,G,T*P,C].  Projection, validity, first-valid-view
@@ -253,6 +260,8 @@ def sampling_4d(sample_points, mlvl_feats, scale_weights, lidar2img, image_h, im
     v = cy / hz / image_h
     valid = (homo > eps) & (v > 0.0) & (v < 1.0) & (u > 0.0) & (u < 1.0)
     i_view = torch.argmax(valid.to(torch.uint8), dim=2, keepdim=True)                 # first valid / 0
+    if view_in is not None:   # imposed camera choice, u8 [S=(b,t,g),Q,P] -> [B,T,1,Q,GP]
+        i_view = view_in.long().view(B, T, G, Q, P).permute(0, 1, 3, 2, 4).reshape(B, T, 1, Q, G * P)
     u_sel = torch.gather(u, 2, i_view)[:, :, 0]
     v_sel = torch.gather(v, 2, i_view)[:, :, 0]                                      # [B,T,Q,GP]
     loc = torch.stack([u_sel, v_sel, i_view[:, :, 0].to(u.dtype) / (N - 1)], dim=-1)

@@ -8,8 +8,8 @@ import pytest
 import torch
 
 from oracle import restate as R
-from parity import (attributed_mask, attribution, decode_parity, decoder_parity, detections_parity, flipped_queries,
-                    head_boxes_normalised, layer_centres, oracle_decoder_with_views, teacher_forced_layer_check)
+from parity import (decode_parity, decoder_parity, detections_parity, head_boxes_normalised, oracle_decoder,
+                    run_with_reference_views, teacher_forced_layer_check)
 from racformer_amd import synthetic as syn
 
 POST_RANGE = (-61.2, -61.2, -10.0, 61.2, 61.2, 10.0)
@@ -61,32 +61,34 @@ def test_head_init_query(golden_dir):
         assert torch.equal(w[:, :2], t(g["generate_points"])), name
 
 
-def run_head(cfg, g):
+def run_head(cfg, g, what):
+    """oracle head_forward with the fixture's camera choices -> (outputs, head state dict)."""
     seed, wseed = int(g["seed"]), int(g["weight_seed"])
     tr_sd = syn.make_state_dict(cfg, wseed)
     head_sd = {"init_query_bbox.weight": syn.make_queries(cfg, seed)[0][0], "label_enc.weight": t(g["label_enc"])}
-    R.LOC_TAP = []
-    try:
-        with torch.no_grad():
-            out = R.head_forward(head_sd, tr_sd, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
-                                 syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg)
-        views = torch.stack([R.views_of(l, cfg.num_cams) for l in R.LOC_TAP])
-    finally:
-        R.LOC_TAP = None
-    return out, views, head_sd
+
+    def run(force):
+        R.LOC_TAP = []
+        R.VIEW_FORCE = [np.asarray(v) for v in force] if force is not None else None
+        try:
+            with torch.no_grad():
+                out = R.head_forward(head_sd, tr_sd, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
+                                     syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg)
+            views = torch.stack([R.views_of(l, cfg.num_cams) for l in R.LOC_TAP])
+        finally:
+            R.LOC_TAP = R.VIEW_FORCE = None
+        return out, views
+
+    (out, _), _ = run_with_reference_views(run, g["views"], what)
+    return out
 
 
-def check_head(cfg, g, out, views, head_sd, what):
-    """Decoder outputs (normalised space, flips attributed), strict decode on the reference's own head outputs, and the
+def check_head(cfg, g, out, what):
+    """Decoder outputs (normalised space, camera choices equal), strict decode on the reference's own head outputs, and the
     end-to-end detections."""
-    flips = flipped_queries(views, g["views"], cfg.num_frames, cfg.num_groups)
     ref_box_n = head_boxes_normalised(g["all_bbox_preds"], cfg.pc_range)
-    # (columns of the head layout: cx cy w l cz h ...; the attribution only needs the centres)
-    centres_in = torch.stack([ref_box_n[..., 0], ref_box_n[..., 1]], dim=-1)
-    qb0 = head_sd["init_query_bbox.weight"][None]
-    att = attributed_mask(flips, layer_centres(qb0, centres_in, cfg.pc_range))
     rows = decoder_parity(out["all_cls_scores"], head_boxes_normalised(out["all_bbox_preds"], cfg.pc_range),
-                          g["all_cls_scores"], ref_box_n, what=what, attributed=att)
+                          g["all_cls_scores"], ref_box_n, what=what)
     ref_det = dict(bboxes=g["det_boxes"], scores=g["det_scores"], labels=g["det_labels"])
     rcls, rbox = t(g["all_cls_scores"])[-1, 0], t(g["all_bbox_preds"])[-1, 0]
     strict = R.nms_free_decode(rcls, rbox, 300, cfg.num_classes, 0.05, POST_RANGE)
@@ -98,32 +100,28 @@ def check_head(cfg, g, out, views, head_sd, what):
 
 def test_head_forward_small6(golden_dir):
     g = load(golden_dir, "head_small6.npz")
-    out, views, head_sd = run_head(syn.SMALL6, g)
-    check_head(syn.SMALL6, g, out, views, head_sd, "head small6")
+    check_head(syn.SMALL6, g, run_head(syn.SMALL6, g, "head small6"), "head small6")
 
 
 def test_head_forward_f8(golden_dir):
     g = load(golden_dir, "head_f8.npz")
     torch.set_num_threads(min(16, os.cpu_count()))
-    out, views, head_sd = run_head(syn.F8, g)
-    check_head(syn.F8, g, out, views, head_sd, "head f8")
+    check_head(syn.F8, g, run_head(syn.F8, g, "head f8"), "head f8")
 
 
 @pytest.mark.parametrize("name,cfg", [("decoder_f8_s1.npz", syn.F8), ("decoder_f8_s2.npz", syn.F8), ("decoder_f8_s3.npz", syn.F8),
                                       ("decoder_f8_3cam_s1.npz", syn.F8_3CAM)])
 def test_decoder_f8_more_seeds(golden_dir, name, cfg):
-    """More seeds of the full-size decoder: literal criterion (argmax identical, boxes within 1e-3 in normalised units)
-    for every query not touched by a shown first-valid-view flip (tests/parity.py)."""
+    """More seeds of the full-size decoder under the free-running criterion of tests/parity.py (camera choices equal)."""
     g = load(golden_dir, name)
     seed, wseed = int(g["seed"]), int(g["weight_seed"])
     torch.set_num_threads(min(16, os.cpu_count()))
     sd = syn.make_state_dict(cfg, wseed)
     qb, qf = syn.make_queries(cfg, seed)
-    cls, box, views = oracle_decoder_with_views(R, sd, qb, qf, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
-                                                syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg)
-    att, nflips = attribution(views, g["views"], qb, g["box"], cfg)
-    print(f"{name}: view flips per layer {nflips}")
-    decoder_parity(cls, box, g["cls"], g["box"], what=name, attributed=att)
+    (cls, box, _), _ = run_with_reference_views(
+        lambda force: oracle_decoder(R, sd, qb, qf, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
+                                     syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg, None, force), g["views"], name)
+    decoder_parity(cls, box, g["cls"], g["box"], what=name)
 
 
 def test_decoder_f8_teacher_forced(golden_dir):

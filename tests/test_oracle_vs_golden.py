@@ -8,7 +8,7 @@ import torch
 
 from oracle import restate as R
 from racformer_amd import synthetic as syn
-from parity import attribution, decoder_parity, oracle_decoder_with_views
+from parity import decoder_parity, oracle_decoder, run_with_reference_views
 
 
 def load(golden_dir, name):
@@ -82,27 +82,31 @@ def test_msda(golden_dir, force_torch):
 
 
 def _run_decoder(cfg, g, stages=None):
-    """-> cls, box, attributed mask (queries touched by a shown first-valid-view flip, tests/parity.py)."""
+    """-> cls, box of the oracle with the camera choices of the fixture (its own, unless some differ: tests/parity.py)."""
     seed, wseed = int(g["seed"]), int(g["weight_seed"])
     sd = syn.make_state_dict(cfg, wseed)
     qb, qf = syn.make_queries(cfg, seed)
-    cls, box, views = oracle_decoder_with_views(R, sd, qb, qf, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
-                                                syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg, stages)
-    att, nflips = attribution(views, g["views"], qb, g["box"], cfg)
-    print("view flips per layer:", nflips)
-    return cls, box, att
+
+    def run(force):
+        if stages is not None:
+            del stages[:]
+        return oracle_decoder(R, sd, qb, qf, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0), syn.make_bev(cfg, seed, 1),
+                              syn.make_img_metas(cfg), cfg, stages, force)
+
+    (cls, box, _), _ = run_with_reference_views(run, g["views"], "oracle")
+    return cls, box
 
 
 @pytest.mark.parametrize("name,cfg", [("decoder_small.npz", syn.SMALL), ("decoder_small6.npz", syn.SMALL6)])
 def test_decoder_small(golden_dir, name, cfg):
     g = load(golden_dir, name)
     stages = []
-    cls, box, att = _run_decoder(cfg, g, stages)
+    cls, box = _run_decoder(cfg, g, stages)
     for li, tol in ((0, 1e-4), (cfg.num_layers - 1, 1e-3)):
         for s in ("position_encoder", "self_attn", "sampling_radar_bev", "sampling_lss_bev", "sampling",
                   "mixing", "ffn"):
             assert_close(stages[li][s], g[f"{s}_L{li}"], tol, tol, f"{s} L{li}")
-    decoder_parity(cls, box, g["cls"], g["box"], what=name, attributed=att, tail_frac=0.0)
+    decoder_parity(cls, box, g["cls"], g["box"], what=name, tail_budget=None)
 
 
 @pytest.mark.parametrize("name,cfg", [("decoder_f8.npz", syn.F8), ("decoder_f8_3cam.npz", syn.F8_3CAM)])
@@ -111,5 +115,5 @@ def test_decoder_f8(golden_dir, name, cfg):
     1e-3, class argmax bit-exact -- for the oracle against the reference CPU forward."""
     g = load(golden_dir, name)
     torch.set_num_threads(min(16, os.cpu_count()))
-    cls, box, att = _run_decoder(cfg, g)
-    decoder_parity(cls, box, g["cls"], g["box"], what=name, attributed=att)
+    cls, box = _run_decoder(cfg, g)
+    decoder_parity(cls, box, g["cls"], g["box"], what=name)

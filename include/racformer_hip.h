@@ -118,7 +118,8 @@ int rac_box_prep_fwd(const float *query_bbox, float *table, int num_boxes, const
  *   loc_out,w_out: optional debug outputs [S,Q,P,3] (u,v,view/(N-1)) and [S,Q,P,L] (NULL,NULL to skip)
  *   view_in      : optional device u8 [S,Q,P]: the camera index to sample each point in, INSTEAD of the first valid view
  *                  (sparsebev_sampling.py:97-110).  NULL on the product path; parity tests pass the reference's own
- *                  choices to take the path's one discontinuous step out of a comparison.
+ *                  choices to take the path's one discontinuous step out of a comparison.  loc_out then still reports
+ *                  the kernel's OWN choice in its third component (and the imposed view's u, v).
  *   pc_range (6), depth_base (D = torch.linspace(-d_region,d_region,D)): HOST pointers */
 int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox,
                        const float *box_table, const float *offsets, const float *ray_logits, const float *scale_logits,

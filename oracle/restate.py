@@ -259,13 +259,15 @@ def project_select(points, lidar2img, image_h, image_w, eps=1e-5, force_view=Non
     v = cam[1] / hz / image_h
     valid = (homo > eps) & (v > 0.0) & (v < 1.0) & (u > 0.0) & (u < 1.0)   # [B,T,N,Q,GP]
     validf = valid.float().permute(0, 1, 3, 4, 2)              # [B,T,Q,GP,N]
-    i_view = torch.argmax(validf, dim=-1)                      # first valid, 0 if none
+    i_view = own_view = torch.argmax(validf, dim=-1)           # first valid, 0 if none
     if force_view is not None:
         i_view = force_view.long()
     idx = i_view[..., None]
     u_sel = torch.gather(u.permute(0, 1, 3, 4, 2), -1, idx)[..., 0]
     v_sel = torch.gather(v.permute(0, 1, 3, 4, 2), -1, idx)[..., 0]
     loc = torch.stack([u_sel, v_sel, i_view.float() / (N - 1)], dim=-1)
+    if LOC_TAP is not None:   # tests: (u, v) as sampled + this implementation's OWN camera choice, slot-major [S,Q,P,3]
+        LOC_TAP.append(torch.stack([u_sel, v_sel, own_view.float() / (N - 1)], dim=-1))
     return loc, i_view, valid.any(dim=2)
 
 
@@ -281,8 +283,8 @@ def sampling_4d(sample_points, feats_cl, scale_weights, lidar2img, image_h, imag
     loc, _, _ = project_select(sample_points.reshape(B, Q, T, G * P, 3), lidar2img, image_h,
                                image_w, eps, force)
     loc = loc.reshape(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * T * G, Q, P, 3)
-    if LOC_TAP is not None:           # tests: the locations handed to the msmv op, one [S,Q,P,3] tensor per call
-        LOC_TAP.append(loc.clone())
+    if LOC_TAP is not None:           # (project_select appended [B,T,Q,GP,3]: bring it to the op's slot order [S,Q,P,3])
+        LOC_TAP[-1] = LOC_TAP[-1].reshape(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * T * G, Q, P, 3)
     L = scale_weights.shape[-1]
     w = scale_weights.reshape(B, Q, G, T, P, L).permute(0, 2, 3, 1, 4, 5).reshape(B * G * T, Q, P, L)
     out = msmv_gather(feats_cl, loc.contiguous(), w.contiguous())      # [S,Q,C,P]

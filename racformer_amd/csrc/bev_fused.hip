@@ -18,7 +18,6 @@
 // For B>1 the reference pairs value frame i=b*T+t with the locations of (t'=i/B, b'=i%B)
 // (bev_self_attention.py:185-188 vs :162,173, quirk Q2); reproduced as written.
 #include "rac_common.h"
-#include <stdlib.h>
 
 #define BEV_MAX_DEPTH 16
 #define BEV_TWO_PI 6.283185307179586f
@@ -321,8 +320,7 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
     a.B = B; a.T = T; a.Q = Q; a.heads = heads; a.NP = NP; a.D = D; a.P = P; a.H = H; a.W = W;
     a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale; a.ld_queue = ld_queue;
     a.blocks_per_b = (Q * heads + BEV_GI - 1) / BEV_GI;
-    static const int xcd_remap = getenv("RAC_BEV_XCD_REMAP") ? atoi(getenv("RAC_BEV_XCD_REMAP")) : 1;
-    a.xcd_remap = xcd_remap;
+    a.xcd_remap = 1;
     const int nb = B * a.blocks_per_b;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RAC_F32)

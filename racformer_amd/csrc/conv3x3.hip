@@ -367,119 +367,6 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv3x3s2_c64_f16x3_kernel(cons
     }
 }
 
-// ------------------------------------------------------------------------------------------------ GEMM
-// The same inner loop as a plain split-precision GEMM  out[M][N] = alpha * (A @ W^T) + bias  (the convolution with one
-// tap): A image [M][K/32][hi 32 | lo 32] f16 (written by rac_rowgemm_fwd), W image [K/32][N][hi 32 | lo 32] f16 (packed
-// once).  Used for AdaptiveMixing's parameter generator (900 x 256 -> 65536): tile 256 x 256, the row tiles of one column
-// tile are adjacent block ids (they share the 256 KB weight tile), 8 K-steps.
-struct GemmArgs {
-    const uint4 *a;
-    const uint4 *w;
-    const float *bias;
-    float *out;
-    int M, N, chunks, ld_out;
-    float alpha;
-};
-
-__global__ __launch_bounds__(512, 1) void gemm_f16x3_kernel(const GemmArgs a)
-{
-    extern __shared__ uint4 lds4[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int chunks = a.chunks, KS = chunks;
-    const int row_tiles = (a.M + CV_TM - 1) / CV_TM, ntiles = row_tiles * (a.N / CV_COUT);
-    // persistent: one workgroup per CU walks tiles t, t + grid, ...; the row tiles of one column tile are adjacent tile
-    // ids (they share the 256 KB weight tile, fetched by different CUs at the same time), and a tile's epilogue stores
-    // drain under the next tile's loads and MFMAs
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row_tile = tile % row_tiles, col_tile = tile / row_tiles;
-    auto row_base = [&](int j) -> size_t {
-        int r = row_tile * CV_TM + (tid >> 3) + 64 * j;
-        r = r < a.M ? r : a.M - 1;                       // rows past M re-read the last row; never stored
-        return (size_t)r * chunks * 8 + (tid & 7);
-    };
-    auto row_slot = [&](int j) -> int {
-        const int r = (tid >> 3) + 64 * j;
-        return r * 8 + ((tid & 7) ^ ((r >> 1) & 7));
-    };
-    const size_t a_base0 = row_base(0), a_base1 = row_base(1), a_base2 = row_base(2), a_base3 = row_base(3);
-    const int st0 = row_slot(0), st1 = row_slot(1), st2 = row_slot(2), st3 = row_slot(3);
-    const uint4 *wtile = a.w + (size_t)col_tile * CV_COUT * 8 + tid;
-    const size_t wstep = (size_t)a.N * 8;              // uint4 per K-step of the weight image
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define GM_GLOAD(ks_)                                                                          \
-    do {                                                                                       \
-        const size_t off_ = (size_t)(ks_) * 8;                                                 \
-        const uint4 *wsrc_ = wtile + (size_t)(ks_) * wstep;                                    \
-        ra0 = a.a[a_base0 + off_]; ra1 = a.a[a_base1 + off_];                                  \
-        ra2 = a.a[a_base2 + off_]; ra3 = a.a[a_base3 + off_];                                  \
-        rb0 = wsrc_[0]; rb1 = wsrc_[512]; rb2 = wsrc_[1024]; rb3 = wsrc_[1536];                \
-    } while (0)
-
-    cv_f4 acc[8][4];
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-            acc[m][nn] = (cv_f4){0.f, 0.f, 0.f, 0.f};
-    int bidx_h[4], bidx_l[4];
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-        const int row = 64 * wn + 16 * nn + li, f = (row >> 1) & 7;
-        bidx_h[nn] = 2048 + row * 8 + (lk ^ f);
-        bidx_l[nn] = 2048 + row * 8 + ((4 + lk) ^ f);
-    }
-    const int arow0 = 128 * wm + li;
-
-    GM_GLOAD(0);
-    CV_LSTORE(0);
-    GM_GLOAD(KS > 1 ? 1 : 0);
-    __syncthreads();
-    for (int ks = 0; ks < KS; ++ks) {
-        CV_LSTORE((ks + 1) & 1);
-        const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
-        GM_GLOAD(kn);
-        const cv_h8 *S = reinterpret_cast<const cv_h8 *>(lds4 + (ks & 1) * CV_STAGE_U4);
-        cv_h8 bh[4], bl[4];
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
-            bh[nn] = S[bidx_h[nn]];
-            bl[nn] = S[bidx_l[nn]];
-        }
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int row = arow0 + 16 * m, f = (row >> 1) & 7;
-            const cv_h8 ah = S[row * 8 + (lk ^ f)];
-            const cv_h8 al = S[row * 8 + ((4 + lk) ^ f)];
-#pragma unroll
-            for (int nn = 0; nn < 4; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nn], acc[m][nn], 0, 0, 0);
-#pragma unroll
-            for (int nn = 0; nn < 4; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nn], acc[m][nn], 0, 0, 0);
-#pragma unroll
-            for (int nn = 0; nn < 4; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nn], acc[m][nn], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-        const int col = col_tile * CV_COUT + 64 * wn + 16 * nn + li;
-        const float bv = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row_tile * CV_TM + 128 * wm + 16 * m + 4 * lk + r;
-                if (row < a.M)
-                    a.out[(size_t)row * a.ld_out + col] = acc[m][nn][r] * a.alpha + bv;
-            }
-    }
-    __syncthreads();   // every wave is past its LDS reads before the next tile's first stage is written
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ C-ABI
 extern "C" int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float floor_value, float *amax_out,
                               void *stream)
@@ -541,39 +428,6 @@ extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias
     }
     hipLaunchKernelGGL(conv3x3_f16x3_kernel, dim3((unsigned)(N * (H * W / CV_TM))), dim3(512), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_conv3x3_fwd");
-}
-
-extern "C" int rac_gemm_f16x3_fwd(const void *a_img, const void *w_img, const float *bias, float alpha, float *out, int ld_out,
-                                  int M, int N, int K, void *stream)
-{
-    RAC_CHECK_ARG(M >= 0 && N > 0 && N % CV_COUT == 0 && K > 0 && K % 32 == 0 && ld_out >= N,
-                  "rac_gemm_f16x3_fwd: M=%d N=%d (multiple of %d) K=%d (multiple of 32) ld_out=%d", M, N, CV_COUT, K, ld_out);
-    if (M == 0)
-        return 0;
-    RAC_CHECK_ARG(a_img && w_img && out, "rac_gemm_f16x3_fwd: null pointer");
-    GemmArgs g;
-    g.a = reinterpret_cast<const uint4 *>(a_img);
-    g.w = reinterpret_cast<const uint4 *>(w_img);
-    g.bias = bias; g.out = out; g.M = M; g.N = N; g.chunks = K / 32; g.ld_out = ld_out; g.alpha = alpha;
-    const int lds = 2 * CV_STAGE_U4 * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    int ntiles = ((M + CV_TM - 1) / CV_TM) * (N / CV_COUT), cus = 256;
-    hipDeviceProp_t prop;
-    static int cached_cus = 0;
-    if (!cached_cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cached_cus = prop.multiProcessorCount;
-        else
-            cached_cus = cus;
-    }
-    cus = cached_cus;
-    hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(512), lds, (hipStream_t)stream, g);
-    return rac_launch_status("rac_gemm_f16x3_fwd");
 }
 
 extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha,

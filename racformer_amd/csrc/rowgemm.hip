@@ -16,7 +16,6 @@
 // statistics in registers); the weights stream from L2 straight into MFMA operands (torch's [out][in] layout, one
 // 16-byte load feeds four k-steps); arithmetic is v_mfma_f32_16x16x4_f32 -- exact fp32, bit-for-bit an fmaf chain.
 #include "rac_common.h"
-#include <stdlib.h>
 
 typedef float rg_f4 __attribute__((ext_vector_type(4)));
 
@@ -138,19 +137,12 @@ __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, flo
                         rac_split_f16(v.y * g.split_scale, hi.y, lo.y);
                         rac_split_f16(v.z * g.split_scale, hi.z, lo.z);
                         rac_split_f16(v.w * g.split_scale, hi.w, lo.w);
-                        if (g.split_layout == RAC_SPLIT_CHUNKED) {
-                            // [8 chunks][hi 32 | lo 32]: the A image of rac_gemm_f16x3_fwd (lane's 4 columns sit in one chunk)
-                            _Float16 *dst = reinterpret_cast<_Float16 *>(g.split_out) + (size_t)row * 512 + (lane >> 3) * 64 + (lane & 7) * 4;
-                            *reinterpret_cast<rac_h4 *>(dst) = hi;
-                            *reinterpret_cast<rac_h4 *>(dst + 32) = lo;
-                        } else {
-                            _Float16 *dst = reinterpret_cast<_Float16 *>(g.split_out) + (size_t)row * (768 + g.split_pad);
-                            *reinterpret_cast<rac_h4 *>(dst + lane * 4) = hi;
-                            *reinterpret_cast<rac_h4 *>(dst + 256 + lane * 4) = hi;
-                            *reinterpret_cast<rac_h4 *>(dst + 512 + lane * 4) = lo;
-                            if (lane < g.split_pad)
-                                dst[768 + lane] = lane < 2 ? (_Float16)g.split_scale : (_Float16)0.f;
-                        }
+                        _Float16 *dst = reinterpret_cast<_Float16 *>(g.split_out) + (size_t)row * (768 + g.split_pad);
+                        *reinterpret_cast<rac_h4 *>(dst + lane * 4) = hi;
+                        *reinterpret_cast<rac_h4 *>(dst + 256 + lane * 4) = hi;
+                        *reinterpret_cast<rac_h4 *>(dst + 512 + lane * 4) = lo;
+                        if (lane < g.split_pad)
+                            dst[768 + lane] = lane < 2 ? (_Float16)g.split_scale : (_Float16)0.f;
                     }
                 }
             }
@@ -248,24 +240,11 @@ extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void
         max_seg = d.num_seg > max_seg ? d.num_seg : max_seg;
     }
     a.rows = rows;
-    // Row-tile height for single-segment GEMMs: RAC_ROWGEMM_MT = 1 (16 rows), 2 (32) or 4 (64) for N >= 512 -- taller tiles
-    // re-read the weights fewer times but leave fewer, longer workgroups.  Default 1 (measured: see DESIGN.md section 3.8).
-    static const int mt_env = getenv("RAC_ROWGEMM_MT") ? atoi(getenv("RAC_ROWGEMM_MT")) : 1;
-    const int MT = (max_seg == 1 && max_n >= 512 && (mt_env == 2 || mt_env == 4)) ? mt_env : 1;
-    const int R = 16 * MT;
+    const int R = 16;
     const size_t lds = (size_t)R * (256 * max_seg + 4) * sizeof(float);
     const dim3 grid((rows + R - 1) / R, (max_n + 63) / 64, num);
     hipStream_t st = (hipStream_t)stream;
-    if (MT == 4) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rowgemm_kernel<1, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((rowgemm_kernel<1, 4, true>), grid, dim3(256), lds, st, a);
-    } else if (MT == 2)
-        hipLaunchKernelGGL((rowgemm_kernel<1, 2, true>), grid, dim3(256), lds, st, a);
-    else if (max_seg == 1 && (long)grid.x * grid.y * grid.z > 512)
+    if (max_seg == 1 && (long)grid.x * grid.y * grid.z > 512)
         hipLaunchKernelGGL((rowgemm_kernel<1, 1, false>), grid, dim3(256), lds, st, a);   // many workgroups: occupancy first
     else if (max_seg == 1)
         hipLaunchKernelGGL((rowgemm_kernel<1, 1, true>), grid, dim3(256), lds, st, a);

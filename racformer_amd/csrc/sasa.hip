@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void sasa_d32_kernel(const SasaArgs a)
 // Matrix-core version (default): QK^T and PV on v_mfma_f32_16x16x4_f32 (exact fp32).
 // Workgroup = 16 queries of one (batch, head); its 4 waves take the 16-key tiles round-robin.
 //   S^T tile [16 keys x 16 queries] = K_tile (A operand) . Q^T (B operand): 8 MFMAs.  With the k index of
-//   a group of four steps assigned as k = 16u + 4*lk + i (see rowmlp.h) every operand is a 16-byte load.
+//   a group of four steps assigned as k = 16u + 4*lk + i (as in rowgemm.hip) every operand is a 16-byte load.
 //   The accumulator then holds S^T[key = 4*lk + r][query = li] -- exactly the B-operand layout of the
 //   second product O^T[32 ch x 16 queries] = V^T (A operand) . P^T (B operand), so the probabilities go
 //   from the first product's accumulators into the second product's operands without leaving registers.

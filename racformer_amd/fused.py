@@ -298,63 +298,6 @@ def pe_head(x3, linear, norm):
     return out
 
 
-class LayerTailWeights:
-    """Pointer table of the decoder-layer tail weights for rac_layer_tail_fwd (native nn.Linear layout; only
-    the two 10-wide heads are copied, zero-padded to 16 rows), built once per forward (the six layers share
-    the weights).  Holds the tensors alive."""
-
-    def __init__(self, layer):
-        def t(lin, pad_to=None):
-            w = lin.weight.detach().contiguous()               # native [out][in]
-            b = lin.bias.detach().contiguous()
-            if pad_to is not None and w.shape[0] < pad_to:
-                w = torch.cat([w, w.new_zeros(pad_to - w.shape[0], w.shape[1])], dim=0).contiguous()
-                b = torch.cat([b, b.new_zeros(pad_to - b.shape[0])]).contiguous()
-            return [w, b]
-
-        def ln(norm):
-            return [norm.weight.detach().contiguous(), norm.bias.detach().contiguous()]
-
-        rb, lb, cb, rg = layer.sampling_radar_bev, layer.sampling_lss_bev, layer.cls_branch, layer.reg_branch
-        self.tensors = (t(rb.attention.output_proj) + t(lb.attention.output_proj)
-                        + [layer.mixing.out_proj.bias.detach().contiguous()]
-                        + ln(layer.norm_radar_bev) + ln(layer.norm_lss_bev) + ln(layer.norm2)
-                        + t(layer.fusion) + ln(layer.norm_fusion)
-                        + t(layer.ffn.layers[0][0]) + t(layer.ffn.layers[1]) + ln(layer.norm3)
-                        + t(cb[0]) + ln(cb[1]) + t(cb[3]) + ln(cb[4]) + t(cb[6], 16)
-                        + t(rg[0]) + t(rg[2]) + t(rg[4], 16))
-        assert len(self.tensors) == 37
-        self.table = (ctypes.c_void_p * 37)(*[x.data_ptr() for x in self.tensors])
-        self.num_classes = cb[6].weight.shape[0]
-        self.code_size = rg[4].weight.shape[0]
-        self.eps = float(layer.norm3.eps)
-
-
-def layer_tail_fused(tw, x1, bev_r, bev_l, partials, query_bbox, time_diff_safe, num_ray):
-    """-> (x3 [B,Q,256], cls [B,Q,num_classes], bbox_pred [B,Q,10], bbox_xy [B,Q,10])."""
-    x1, bev_r, bev_l, partials, query_bbox = (v.contiguous() for v in (x1, bev_r, bev_l, partials, query_bbox))
-    _lib.require_gpu(x1, bev_r, bev_l, partials, query_bbox, time_diff_safe, what="layer_tail_fused")
-    B, Q, E = x1.shape
-    if E != 256:
-        raise RuntimeError("layer_tail_fused: embed_dims must be 256")
-    S = partials.shape[0]
-    x3 = torch.empty_like(x1)
-    cls = torch.empty(B, Q, tw.num_classes, device=x1.device, dtype=torch.float32)
-    pred, xy = torch.empty(B, Q, 10, device=x1.device), torch.empty(B, Q, 10, device=x1.device)
-    acts = (ctypes.c_void_p * 10)(x1.data_ptr(), bev_r.data_ptr(), bev_l.data_ptr(), partials.data_ptr(),
-                                  query_bbox.data_ptr(), time_diff_safe.data_ptr(), x3.data_ptr(), cls.data_ptr(),
-                                  pred.data_ptr(), xy.data_ptr())
-    ev = _lib.timer.record("layer_tail_fwd") if _lib.timer is not None else None
-    if ev:
-        ev[0].record()
-    rc = _lib.lib().rac_layer_tail_fwd(acts, tw.table, S, B * Q * E, B, Q, time_diff_safe.shape[1], tw.num_classes,
-                                       tw.code_size, float(num_ray), tw.eps, _lib.stream_ptr())
-    if ev:
-        ev[1].record()
-    _lib.check(rc, "rac_layer_tail_fwd")
-    return x3, cls, pred, xy
-
-
 # ------------------------------------------------------------------------------------------- 3x3 convolution
 def pack_conv3x3_weight(weight, cout=256):
     """nn.Conv2d weight [cout, Cin, 3, 3] fp32 -> (ws f16 [9, Cin/32, cout, 2, 32], w_alpha) for rac_conv3x3_fwd (cout 256) /
@@ -508,12 +451,11 @@ def _rows2d(t, what):
 
 
 def row_seg(a, num_partials=1, a_scale=1.0, bias0=None, residual=None, norm=None, relu=False, post=None, x_out=None,
-            split_out=None, split_chunked=False):
+            split_out=None):
     """One 256-wide segment of a rowgemm's A operand (see rac_rowgemm_fwd):
     [relu](LN_norm(a_scale * sum_p a[p] + bias0 + residual)) [+ post]; ``a`` is [rows,256] (any row stride) or, with
     num_partials = S > 1, a contiguous [S, rows, 256].  ``x_out`` / ``split_out``: destinations for the finished rows
-    (fp32 [rows,256] / f16 [rows, 768 + SPLIT_BIAS_PAD], or f16 [rows, 512] = [8 chunks][hi 32 | lo 32] with
-    ``split_chunked``: the A image of ``gemm_f16x3``)."""
+    (fp32 [rows,256] / f16 [rows, 768 + SPLIT_BIAS_PAD])."""
     g = _lib.RowSeg()
     keep = []
     if num_partials > 1:
@@ -543,11 +485,11 @@ def row_seg(a, num_partials=1, a_scale=1.0, bias0=None, residual=None, norm=None
         t, g.x_out, g.ld_xout = _rows2d(x_out, "x_out")
         keep.append(t)
     if split_out is not None:
-        width = 512 if split_chunked else 768 + SPLIT_BIAS_PAD
+        width = 768 + SPLIT_BIAS_PAD
         if split_out.dtype != torch.float16 or not split_out.is_contiguous() or split_out.shape[-1] != width:
             raise RuntimeError(f"row_seg: split_out must be a contiguous f16 [rows, {width}] tensor")
         g.split_out, g.split_scale = ctypes.c_void_p(split_out.data_ptr()), SPLIT_ACT_SCALE
-        g.split_pad, g.split_layout = (0, 1) if split_chunked else (SPLIT_BIAS_PAD, 0)
+        g.split_pad, g.split_layout = SPLIT_BIAS_PAD, 0
         keep.append(split_out)
     g._keep = keep
     return g
@@ -577,38 +519,6 @@ def rowgemm_launch(descs, rows):
     arr = (_lib.RowGemm * len(descs))(*descs)
     rc = _lib.lib().rac_rowgemm_fwd(arr, len(descs), int(rows), _lib.stream_ptr())
     _lib.check(rc, "rac_rowgemm_fwd")
-
-
-# ------------------------------------------------------------------------------------------- split-precision GEMM
-def pack_gemm_weight_f16x3(weight):
-    """nn.Linear weight [N, K] fp32 -> (f16 [K/32, N, 2, 32] = hi / lo of weight * 2^s per 32-wide k chunk, alpha) for
-    rac_gemm_f16x3_fwd; alpha = 2^-s / SPLIT_ACT_SCALE undoes both power-of-two scalings.  (None, None) if f16 cannot
-    hold the weights or the shape does not fit the kernel (N % 256, K % 32)."""
-    import math
-    w = weight.detach().float()
-    N, K = w.shape
-    amax = float(w.abs().max())
-    if N % 256 != 0 or K % 32 != 0 or not (amax > 0.0) or amax != amax or amax == float("inf"):
-        return None, None
-    s = 13 - math.frexp(amax)[1] + 1
-    ws = (w * (2.0 ** s)).view(N, K // 32, 32).permute(1, 0, 2)          # [chunk, n, 32]
-    hi = ws.to(torch.float16)
-    lo = (ws - hi.float()).to(torch.float16)
-    return torch.stack([hi, lo], dim=2).contiguous(), 2.0 ** (-s) / SPLIT_ACT_SCALE
-
-
-def gemm_f16x3(a_img, w_img, bias, alpha):
-    """a_img f16 [M, K/32 * 64] (row_seg(split_chunked=True)), w_img f16 [K/32, N, 2, 32] -> fp32 [M, N] = alpha * A @ W^T + bias."""
-    _lib.require_gpu(a_img, w_img, what="gemm_f16x3")
-    M = a_img.shape[0]
-    chunks, N = w_img.shape[0], w_img.shape[1]
-    if a_img.dtype != torch.float16 or w_img.dtype != torch.float16 or a_img.shape[1] != chunks * 64:
-        raise RuntimeError("gemm_f16x3: operand images do not match")
-    out = torch.empty(M, N, device=a_img.device, dtype=torch.float32)
-    rc = _lib.lib().rac_gemm_f16x3_fwd(_lib.ptr(a_img), _lib.ptr(w_img), _lib.ptr(bias) if bias is not None else None,
-                                       float(alpha), _lib.ptr(out), N, M, N, chunks * 32, _lib.stream_ptr())
-    _lib.check(rc, "rac_gemm_f16x3_fwd")
-    return out
 
 
 # ------------------------------------------------------------------------------------------- decode

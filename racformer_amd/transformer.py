@@ -25,9 +25,9 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, gemm_f16x3, layer_boundary_fused,
-                    pack_gemm_weight_f16x3, conv3x3_fused, gru_gate_fused, pack_conv3x3_weight, row_gemm, row_seg, rowgemm_launch, upsample2x_fused, LayerTailWeights, add_ln, bev_sampling_fused, box_prep, layer_tail_fused, mixing_fused,
-                    pe_head, refine_fused, sampling4d_fused, sasa_fused, split_weight_f16)
+from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add_ln, bev_sampling_fused, box_prep,
+                    gru_gate_fused, layer_boundary_fused, mixing_fused, pack_conv3x3_weight, pe_head, refine_fused, row_gemm,
+                    row_seg, rowgemm_launch, sampling4d_fused, sasa_fused, split_weight_f16, upsample2x_fused)
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -565,7 +565,7 @@ class BEVSampling(nn.Module):
         nn.init.uniform_(bias[:, 0:2], -0.5, 0.5)
         self.attention.init_weights()
 
-    def prepare_value(self, bev_feats, conv_pack=None, hidden=None):
+    def prepare_value(self, bev_feats, conv_pack=None):
         """Query-independent half of inner_forward (:484-485, :532-537 + value_proj): temporal
         encoder (radar only), + learned positional encoding, value projection.  ``conv_pack``: the packed
         temporal_fusion weights (fused convolution kernel, channel-last output) or None (MIOpen).  With
@@ -575,7 +575,7 @@ class BEVSampling(nn.Module):
         if self.temp_radar and conv_pack is not None and conv_pack.get("ws") is not None and \
                 self.temporal_encoder.fused_conv_supported(bev_feats):
             B, T = bev_feats.shape[:2]
-            nhwc = self.temporal_encoder.forward_channel_last(bev_feats, conv_pack, hidden() if callable(hidden) else hidden)
+            nhwc = self.temporal_encoder.forward_channel_last(bev_feats, conv_pack)
             if conv_pack.get("pixel_bias") is not None:
                 return nhwc.view(B * T, H * W, self.attention.num_heads, -1), (H, W)
             pos = self.positional_encoding.grid(H, W).to(bev_feats.dtype)
@@ -707,11 +707,7 @@ class AdaptiveMixing(nn.Module):
         ow, out_alpha = split_weight_f16(w.detach().view(N, S, self.SPLIT_SLICE).permute(1, 0, 2).reshape(S * N, self.SPLIT_SLICE))
         if ow is None:
             return {}
-        packs = dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow.view(S, N, 3 * self.SPLIT_SLICE), out_alpha=out_alpha)
-        gen_img, gen_img_alpha = pack_gemm_weight_f16x3(gen.weight)       # image of the hand-written GEMM (rac_gemm_f16x3_fwd)
-        if gen_img is not None:
-            packs.update(gen_img=gen_img, gen_img_alpha=gen_img_alpha)
-        return packs
+        return dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow.view(S, N, 3 * self.SPLIT_SLICE), out_alpha=out_alpha)
 
     def out_proj_partials(self, x, query, out_proj_split, params=None, packs=None, query_split=None):
         """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
@@ -729,11 +725,7 @@ class AdaptiveMixing(nn.Module):
             ev = timer.record("mixing_generator_gemm") if timer is not None else None
             if ev:
                 ev[0].record()
-            if split and query_split.shape[-1] == 2 * self.query_dim:
-                # chunked [hi 32 | lo 32] image: the hand-written split-precision GEMM (bias and alpha in its epilogue)
-                params = gemm_f16x3(query_split, packs["gen_img"], self.parameter_generator.bias,
-                                    packs["gen_img_alpha"]).view(B, Q, -1)
-            elif split:
+            if split:
                 # bias rides in the K-concatenated operands; alpha (a power of two) is applied by the mixing kernel
                 params = torch.mm(query_split, packs["gen_w"].t(), out_dtype=torch.float32).view(B, Q, -1)
                 params_scaled = True
@@ -829,31 +821,16 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         self.d_region_list = d_region_list
         self.num_ray = num_ray
         self.fused = True  # False: the reference's op decomposition (torch keypoints + msmv / MSDA operators)
-        # One-launch layer tail (rac_layer_tail_fwd).  Off by default: measured 168 us per layer against ~110 us
-        # for the chain of library GEMMs + add_ln + refine kernels it replaces -- a 16-row tile has to pull the
-        # tail's 3.5 MB of weights through ONE CU's L2 port (~70 GB/s), which bounds it near 50 us + 44 us of MFMA.
-        self.tail_kernel = False
-        # Run the mixing parameter generator (MFMA-bound) on a second stream beside the sampling kernels
-        # (memory-bound).  Measured: no gain on MI355X (92.9 vs 92.7 samples/s) -- the GEMM's workgroups occupy every
-        # CU, the kernels do not co-schedule -- so it stays off.
-        self.overlap = False
         # The mixing generator and out_proj as split-precision f16-MFMA GEMMs (AdaptiveMixing.split_packs).  False: fp32 rocBLAS.
         self.split_gemm = True
         # The ~17 small Linears of the layer with the add / LayerNorm / ReLU before them as rac_rowgemm_fwd launches (the
         # producer's normalisation runs as the prologue of its consumer GEMM): 21 launches per layer instead of ~50.
         # False: library GEMMs + rac_add_ln_fwd launches (forward_fused_chain).
         self.rowgemm = True
-        # parameter generator on the hand-written split-precision GEMM (rac_gemm_f16x3_fwd) instead of hipBLASLt over the
-        # K-concatenated images.  Measured 158 us against 130 us (8 K-steps per 256x256 tile: the two-stage register pipeline
-        # of the convolution kernel does not hide the first-load and store latencies of so short a K loop), so it is off.
-        self.own_gemm = False
         # ((next layer index, box pointer, shape, version), pe_head output, box table, the box tensor) handed from a layer's
         # boundary launch to the next call; the decoder clears it before layer 0, and it is only honoured for the matching
         # layer index and (live, unmodified) tensor
         self._carry = None
-        # the radar and the LSS BEV kernel of a layer on two HIP streams (see forward_fused).  Measured 156.5 vs 160.5 samples/s:
-        # the two kernels contend for the same L2 / Infinity-Cache bandwidth and the stream joins cost more than the overlap; off.
-        self.bev_two_streams = False
         # radar stream: value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack)
         self.compose_radar_value = True
         self._pack_cache = {}
@@ -911,11 +888,6 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
     def _sample(self, qb, x1, mlvl_feats, img_metas, d_region, linear_out, table):
         return self.sampling(qb, x1, mlvl_feats, img_metas, d_region=d_region, linear_out=linear_out, box_table=table)
 
-    def _side_stream(self, device):
-        if getattr(self, "_side", None) is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
-
     def _wide_linears(self):
         """The eleven Linear(256 -> .) layers that all read the post-norm1 query features, as one
         [2189,256] GEMM operand (one rocBLAS call per layer instead of eleven)."""
@@ -927,10 +899,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         widths = [m.weight.shape[0] for m in mods]
         return w, b, widths
 
-    def prepare(self, lss_bev_feats, radar_bev_feats, radar_hidden=None):
-        """Layer-invariant tensors (computed once per forward).  ``radar_hidden``: a callable returning
-        temporal_encoder.hidden_stream(radar_bev_feats) computed elsewhere (it is called right before the result is
-        needed, i.e. after the LSS value stream has been enqueued)."""
+    def prepare(self, lss_bev_feats, radar_bev_feats):
+        """Layer-invariant tensors (computed once per forward)."""
         rbs = self.sampling_radar_bev
         te, up = rbs.temporal_encoder, rbs.temporal_encoder.upsample[1]
         conv_pack = None
@@ -960,7 +930,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             lss_value, lss_hw = lbs.attention.project_value(lss_bev_feats, pos_term=pos_term), (Hl, Wl)
         else:
             lss_value, lss_hw = lbs.prepare_value(lss_bev_feats)
-        radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack, radar_hidden)
+        radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack)
         rb, lb, mix = self.sampling_radar_bev, self.sampling_lss_bev, self.mixing
         wide_mods = [self.sampling.sampling_offset, self.sampling.ray_points_offset, self.sampling.scale_weights]
         for x in (rb, lb):
@@ -976,7 +946,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         sasa_w = self._cached("sasa", [at.attention.attn.in_proj_weight, at.gen_tau.weight, at.attention.attn.in_proj_bias,
                                        at.gen_tau.bias], at.wide_in_proj)
         packs = {}
-        if self.split_gemm and radar_value.is_cuda and self.fused and not self.tail_kernel:   # (the one-launch tail sums raw partials)
+        if self.split_gemm and radar_value.is_cuda and self.fused:
             # |norm1 output| <= sqrt(E) * max|gamma| + max|beta| bounds the generator's A operand
             packs = self._cached("split_packs", [mix.parameter_generator.weight, mix.parameter_generator.bias,
                                                  mix.out_proj.weight, self.norm1.weight, self.norm1.bias], lambda: mix.split_packs(
@@ -984,16 +954,13 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         out_proj_split = None if packs else self._cached("out_proj_split", [mix.out_proj.weight], mix.split_out_proj)
         return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
                     wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=out_proj_split, split_packs=packs,
-                    sasa_w=sasa_w, bev_owt=bev_owt, bev_ob=bev_ob, c0r0_w=c0r0_w, c0r0_b=c0r0_b,
-                    **({"side_stream": self._side_stream(radar_value.device)} if radar_value.is_cuda else {}),
-                    **({"tail": LayerTailWeights(self)} if self.fused and self.tail_kernel and radar_value.is_cuda
-                       and self.embed_dims == 256 and self.code_size == 10 and self.num_classes <= 16 else {}))
+                    sasa_w=sasa_w, bev_owt=bev_owt, bev_ob=bev_ob, c0r0_w=c0r0_w, c0r0_b=c0r0_b)
 
     def forward_fused(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None):
         """The layer as hand-written HIP kernels plus the three big library GEMMs of the mixing: every small Linear is
         a rac_rowgemm_fwd launch whose prologue performs the residual add / split-K sum / LayerNorm / ReLU that
         precedes it in the reference (racformer_transformer.py:239-279); same arithmetic, fp32 throughout."""
-        if not self.rowgemm or (self.tail_kernel and "tail" in prepared) or self.overlap:
+        if not self.rowgemm:
             return self.forward_fused_chain(query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages)
         meta = img_metas[0]
         time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
@@ -1023,37 +990,21 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         rowgemm_launch([row_gemm([row_seg(o)], p.out_proj.weight, p.out_proj.bias, attn)], n)
         # x1 = norm1(x + attn) (+ its f16 image for the generator GEMM);  the eleven Linears of the three sampling modules
         x1 = new(B, Q, E)
-        own_gemm = bool(packs) and self.own_gemm and "gen_img" in packs
-        x1_split = torch.empty(n, 2 * E if own_gemm else 3 * E + SPLIT_BIAS_PAD, device=dev, dtype=torch.float16) if packs else None
+        x1_split = torch.empty(n, 3 * E + SPLIT_BIAS_PAD, device=dev, dtype=torch.float16) if packs else None
         wide = new(B, Q, prepared["wide_w"].shape[0])
-        rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split,
-                                          split_chunked=own_gemm)],
+        rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split)],
                                  prepared["wide_w"], prepared["wide_b"], wide)], n)
         lin = wide.split(prepared["wide_widths"], dim=-1)
         rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
         r_off, r_ray, r_sc, r_qu = lin[3:7]
         l_off, l_ray, l_sc, l_qu = lin[7:11]
         bev = new(2, B, Q, E)
-        side = prepared.get("side_stream") if self.bev_two_streams else None
-        if side is not None:
-            # the two BEV launches are independent and each is one round of workgroups with a latency-bound prologue and
-            # tail: on two streams the second kernel's workgroups fill the CUs as the first one's drain
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
-            bev.record_stream(side)
-            with torch.cuda.stream(side):
-                bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
-                                   lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
-                                   box_table=table, out=bev[1])
         bev_sampling_fused(prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff,
                            rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region,
                            box_table=table, out=bev[0])
-        if side is not None:
-            main.wait_stream(side)
-        else:
-            bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
-                               lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
-                               box_table=table, out=bev[1])
+        bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
+                           lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
+                           box_table=table, out=bev[1])
         sampled_feat = self._sample(qb, x1, mlvl_feats, img_metas, d_region, lin[0:3], table)
         partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)
         p_scale = packs["out_alpha"] if packs else 1.0
@@ -1122,20 +1073,6 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
                                      box_table=table))
         packs = prepared.get("split_packs")
         x1, x1_split = add_ln(attn, self.norm1, residual=x, split=True) if packs else (add_ln(attn, self.norm1, residual=x), None)
-        # The 30-GFLOP parameter generator of AdaptiveMixing needs only x1.  It is MFMA-bound while the three
-        # sampling kernels are memory / L2-bound, so it runs on a second HIP stream beside them.
-        params = None
-        side = prepared.get("side_stream") if self.overlap else None
-        if side is not None:
-            main = torch.cuda.current_stream()
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                params = self.mixing.parameter_generator(x1)
-                done = torch.cuda.Event()
-                done.record(side)
-            params.record_stream(main)
         # the three sampling modules: one wide GEMM, one box table, three fused kernels
         lin = F.linear(x1, prepared["wide_w"], prepared["wide_b"]).split(prepared["wide_widths"], dim=-1)
         rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
@@ -1151,16 +1088,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
                            box_table=table, out=bev[1])
         sampled_feat = self._sample(qb, x1, mlvl_feats, img_metas, d_region, lin[0:3], table)
         # adaptive mixing: generator GEMM -> MFMA kernel -> split-K partial products of out_proj
-        if side is not None:
-            torch.cuda.current_stream().wait_event(done)
-        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], params, packs, x1_split)
+        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)
         p_scale = packs["out_alpha"] if packs else 1.0
-        if stages is None and self.tail_kernel and "tail" in prepared:
-            # everything that remains of the layer in one launch (rac_layer_tail_fwd)
-            x3, cls_score, bbox_pred, bbox_xy = layer_tail_fused(prepared["tail"], x1, bev[0], bev[1], partials, qb,
-                                                                 meta["time_diff_safe"], self.num_ray)
-            self.last_bbox_xy = bbox_xy
-            return x3, cls_score, bbox_pred
         # both BEV output projections as one batched GEMM; the three normalised branches land directly in the
         # [x2 | radar | lss] buffer the fusion Linear reads (no torch.cat)
         proj = torch.baddbmm(prepared["bev_ob"], bev.view(2, B * Q, E), prepared["bev_owt"]).view(2, B, Q, E)
@@ -1277,9 +1206,6 @@ class RaCFormerTransformerDecoder(nn.Module):
         # True: ``mlvl_feats`` arrive already in the sampling layout [B*T*G, N, H, W, C] (a producer that writes the
         # grouped channel-last pyramid directly skips the 1.47 GB regroup)
         self.pregrouped = False
-        # ConvGRU chain on a second stream beside the regroup: measured 143.2 vs 145.6 samples/s (slower) -- the regroup
-        # already saturates HBM and the chain's convolutions then wait on it; stays off.
-        self.overlap_prepare = False
 
     @torch.no_grad()
     def init_weights(self):
@@ -1324,22 +1250,6 @@ class RaCFormerTransformerDecoder(nn.Module):
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
                 stages_per_layer=None):
         self.stage_metas(img_metas, query_bbox.shape[0], query_bbox.device)
-        # The ConvGRU half of the radar temporal encoder is ~25 small launch-bound kernels (downsample, 4 GRU steps, resize,
-        # 3x3 conv): it runs on a second HIP stream beside the HBM-bound pyramid regroup and the LSS value projection.
-        layer = self.decoder_layer
-        te = layer.sampling_radar_bev.temporal_encoder
-        radar_hidden = None
-        if self.overlap_prepare and query_bbox.is_cuda and layer.fused and te.fused_conv_supported(radar_bev_feats):
-            main, side = torch.cuda.current_stream(), layer._side_stream(query_bbox.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                hidden = te.hidden_stream(radar_bev_feats)
-            for t in hidden:
-                t.record_stream(main)
-
-            def radar_hidden():
-                main.wait_stream(side)
-                return hidden
         if self.pregrouped:
             # producer-side layout: the FPN already wrote [B*T*G, N, H, W, C]
             for f in mlvl_feats:
@@ -1349,7 +1259,7 @@ class RaCFormerTransformerDecoder(nn.Module):
             grouped = regroup_pyramid(mlvl_feats, self.num_cams, 4, self.feature_dtype)
             for lvl, g in enumerate(grouped):
                 mlvl_feats[lvl] = g  # the reference mutates the caller's list too (:124)
-        prepared = self.decoder_layer.prepare(lss_bev_feats, radar_bev_feats, radar_hidden)
+        prepared = self.decoder_layer.prepare(lss_bev_feats, radar_bev_feats)
         self.decoder_layer._carry = None
         cls_scores, bbox_preds = [], []
         for i in range(self.num_layers):

@@ -26,7 +26,8 @@ import torch.nn.functional as F
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
 from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add_ln, bev_sampling_fused, box_prep,
-                    gru_gate_fused, layer_boundary_fused, mixing_fused, pack_conv3x3_weight, pe_head, refine_fused, row_gemm,
+                    gru_gate_fused, layer_boundary_fused, mixing_fused, outproj_fused, pack_conv3x3_weight, pack_gemm_split_weight,
+                    pe_head, refine_fused, row_gemm,
                     row_seg, rowgemm_launch, sampling4d_fused, sasa_fused, split_weight_f16, upsample2x_fused)
 from .msda import msda_forward
 from .msmv import msmv_forward
@@ -687,7 +688,7 @@ class AdaptiveMixing(nn.Module):
     SPLIT_SLICE = SPLIT_SLICE   # K slice of out_proj's split-K batches; fixed by rac_mixing_fwd's out_split layout
 
     def split_packs(self, act_bound=None):
-        """-> dict(gen_w [N,3K+8] f16, gen_alpha, out_w [S,256,3*1024] f16, out_alpha), or {} if f16 cannot hold the
+        """-> dict(gen_w [N,3K+64] f16, gen_alpha, out_w (line image [256, K/64, 128] f16), out_alpha, out_slices), or {} if f16 cannot hold the
         operands: a weight or bias overflows, |activation| bound * SPLIT_ACT_SCALE >= 6e4, or the generated
         parameters -- bounded by max_row ||W_row||_1 * act_bound + max|bias| -- could reach the f16 range that
         rac_mixing_fwd's RAC_MIX_F16X3 mode needs for S.  (One-off host reads; the result is cached.)"""
@@ -703,11 +704,10 @@ class AdaptiveMixing(nn.Module):
         gen_w, gen_alpha = split_weight_f16(gen.weight, gen.bias)
         if gen_w is None:
             return {}
-        S = K // self.SPLIT_SLICE
-        ow, out_alpha = split_weight_f16(w.detach().view(N, S, self.SPLIT_SLICE).permute(1, 0, 2).reshape(S * N, self.SPLIT_SLICE))
+        ow, out_alpha = pack_gemm_split_weight(w)        # line image [N, K/64, hi 64 | lo 64] for rac_outproj_fwd
         if ow is None:
             return {}
-        return dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow.view(S, N, 3 * self.SPLIT_SLICE), out_alpha=out_alpha)
+        return dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow, out_alpha=out_alpha, out_slices=K // self.SPLIT_SLICE)
 
     def out_proj_partials(self, x, query, out_proj_split, params=None, packs=None, query_split=None):
         """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
@@ -735,15 +735,14 @@ class AdaptiveMixing(nn.Module):
                 ev[1].record()
         out = mixing_fused(x.contiguous(), params, P, G, self.out_points, split=split,
                            param_scale=packs["gen_alpha"] if split and params_scaled else 1.0, f16x3=split)
+        if split:
+            # hand-written split-K GEMM on the line images; the caller's add_ln applies packs["out_alpha"] to the summed partials
+            return outproj_fused(out, packs["out_w"], packs["out_slices"])
         ev = timer.record("mixing_out_proj_gemm") if timer is not None else None
         if ev:
             ev[0].record()
-        if split:
-            # [S, B*Q, 3k] x [S, 3k, N]; the caller's add_ln applies packs["out_alpha"] to the summed partials
-            partials = torch.bmm(out.transpose(0, 1), packs["out_w"].transpose(1, 2), out_dtype=torch.float32)
-        else:
-            S_, N, k = out_proj_split.shape
-            partials = torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
+        S_, N, k = out_proj_split.shape
+        partials = torch.bmm(out.view(B * Q, S_, k).transpose(0, 1), out_proj_split.transpose(1, 2))
         if ev:
             ev[1].record()
         return partials
@@ -874,7 +873,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             ("mixing_generator_gemm", "parameter_generator GEMM (hipBLASLt f16, K-concatenated hi/lo operands)" if split
              else "parameter_generator GEMM (rocBLAS fp32)",
              2.0 * Qn * E * gen_cols, 2.0 * Qn * gen_cols * ((3 * E + 64) if split else E), 16 if split else 32),
-            ("mixing_out_proj_gemm", "out_proj split-K batched GEMM (hipBLASLt f16, K-concatenated hi/lo operands)" if split
+            ("mixing_out_proj_gemm", "gemm_split_kernel (hand-written split-K GEMM, 3 f16 products, LDS-DMA staging)" if split
              else "out_proj split-K batched GEMM (rocBLAS fp32)",
              2.0 * Qn * (G_ * 128 * C_) * E, 2.0 * Qn * (G_ * 128 * C_) * E * (3 if split else 1), 16 if split else 32),
             ("temporal_fusion_conv", "conv3x3_f16x3_kernel (hand-written implicit GEMM, 3 f16 products; value_proj composed in)",

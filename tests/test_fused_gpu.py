@@ -173,8 +173,9 @@ def test_sasa_kernels_all_sizes(Q):
 
 def test_split_precision_operands_and_gemms():
     """The f16 hi/lo images written by rac_add_ln_fwd / rac_mixing_fwd reproduce the fp32 values to 2^-21, and the
-    K-concatenated 3-product GEMMs built on them match a float64 GEMM as closely as the fp32 GEMM does."""
-    from racformer_amd.fused import SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, add_ln, mixing_fused, split_weight_f16
+    3-product GEMMs built on them (library GEMM over K-concatenated operands for the generator, hand-written rac_outproj_fwd
+    for out_proj) match a float64 GEMM as closely as the fp32 GEMM does."""
+    from racformer_amd.fused import SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, add_ln, mixing_fused, outproj_fused, split_weight_f16
     from racformer_amd.transformer import AdaptiveMixing
     torch.manual_seed(5)
     ln = torch.nn.LayerNorm(256).to(DEV)
@@ -201,18 +202,48 @@ def test_split_precision_operands_and_gemms():
         params = mix.parameter_generator(q)
         z = mixing_fused(x, params, 96, 4, 128)
         z16 = mixing_fused(x, params, 96, 4, 128, split=True)
-        assert tuple(z16.shape) == (64, 32768 // SPLIT_SLICE, 3 * SPLIT_SLICE)
-        zh, zh2, zl = z16.float().view(64, 32768 // SPLIT_SLICE, 3, SPLIT_SLICE).unbind(2)
-        assert torch.equal(zh, zh2)
+        assert tuple(z16.shape) == (64, 4 * 128, 128)                     # line image: [hi 64 | lo 64] per out point
+        zh, zl = z16.float().view(64, 512, 2, 64).unbind(2)
         rec = ((zh.double() + zl.double()) / SPLIT_ACT_SCALE).reshape(64, -1)
         assert (rec - z.view(64, -1).double()).abs().max().item() <= 2.0 ** -21 * z.abs().max().item()
         packs = mix.split_packs()
-        part = torch.bmm(z16.transpose(0, 1), packs["out_w"].transpose(1, 2), out_dtype=torch.float32) * packs["out_alpha"]
+        wh, wl = packs["out_w"].float().view(256, 512, 2, 64).unbind(2)    # the packed weight image holds W * 2^s as hi + lo
+        wrec = (wh.double() + wl.double()).reshape(256, -1) * (packs["out_alpha"] * SPLIT_ACT_SCALE)
+        assert (wrec - mix.out_proj.weight.double()).abs().max().item() <= 2.0 ** -21 * mix.out_proj.weight.abs().max().item()
+        part = outproj_fused(z16, packs["out_w"], packs["out_slices"]) * packs["out_alpha"]
+        assert tuple(part.shape) == (16, 64, 256)
         want = z.view(64, -1).double() @ mix.out_proj.weight.double().t()
         e_split = (part.sum(0).double() - want).abs().max().item()
         e_fp32 = ((z.view(64, -1) @ mix.out_proj.weight.t()).double() - want).abs().max().item()
         assert e_split < 4 * e_fp32 + 1e-6, (e_split, e_fp32)
     assert mix.split_packs(act_bound=1e5) == {}     # operands outside the f16 range: the caller keeps the fp32 GEMMs
+
+
+@pytest.mark.parametrize("M,N,K,S", [(900, 256, 32768, 16), (131, 256, 4096, 2), (7, 100, 1024, 4), (128, 128, 64, 1)])
+def test_outproj_kernel_vs_float64(M, N, K, S):
+    """rac_outproj_fwd (hand-written split-K GEMM, LDS-DMA staging, source-side swizzle) against a float64 GEMM of the values
+    its operand images hold: asymmetric integer-free random operands, ragged M / N (tile edges), every slice checked."""
+    from racformer_amd.fused import outproj_fused
+    g = torch.Generator().manual_seed(M + K)
+    z = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+
+    def image(t):       # [R, K] f32 -> line image [R, K/64, hi 64 | lo 64] f16 and the f64 values it represents
+        hi = t.to(torch.float16)
+        lo = (t - hi.float()).to(torch.float16)
+        img = torch.stack([hi.view(-1, K // 64, 64), lo.view(-1, K // 64, 64)], dim=2).reshape(-1, K // 64, 128).contiguous()
+        return img, hi.double() + lo.double()
+
+    zi, zv = image(z * 16.0)
+    wi, wv = image(w * 1024.0)
+    part = outproj_fused(zi, wi, S)
+    assert tuple(part.shape) == (S, M, N)
+    ks = K // S
+    for s_ in range(S):
+        want = zv[:, s_ * ks:(s_ + 1) * ks] @ wv[:, s_ * ks:(s_ + 1) * ks].t()
+        err = (part[s_].double() - want).abs().max().item()
+        # dropped lo*lo term (2^-22 relative to the hi*hi terms) + fp32 accumulation of ks products
+        assert err <= 3e-6 * float(want.abs().max()) + 1e-6 * float((zv.abs().max() * wv.abs().max())) * ks ** 0.5, (s_, err)
 
 
 @pytest.mark.parametrize("shape", [(8, 128, 128, 256, 64), (3, 16, 16, 256, 64), (2, 32, 64, 32, 32)])

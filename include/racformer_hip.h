@@ -206,23 +206,23 @@ enum {
  *   params : device f32, row q at params + q*ld_params, per group [64*64 (M, in x out) | 128*in_points (S)];
  *            every value is multiplied by param_scale on load (1.0, or the power-of-two alpha of a split GEMM)
  *   out    : device f32 [num_query, groups, 128, 64] (NULL to skip when out_split is given)
- *   out_split : optional device f16 line image [num_query][groups*128][hi 64 | lo 64] of the flattened output row
+ *   out_split : optional device f16 line image [num_query][groups*256][hi 32 | lo 32] of the flattened output row
  *            (K order group, out point, channel) with out*split_scale = hi + lo -- the A operand of rac_outproj_fwd
  *            (NULL to skip) */
 int rac_mixing_fwd(const float *x, const float *params, float param_scale, float *out, void *out_split,
                    float split_scale, int ld_params, int num_query, int groups, int in_points, int channels, int out_points,
                    float eps, int mfma_mode, void *stream);
 
-/* Split-precision GEMM operand image: nn.Linear weight [N][K] f32 -> f16 [N][K/64][hi 64 | lo 64] of weight * scale
- * (per 64 values of K one 256-byte line; hi + lo carry 22 significant bits).  Packed once per set of weights. */
+/* Split-precision GEMM operand image: nn.Linear weight [N][K] f32 -> f16 [N][K/32][hi 32 | lo 32] of weight * scale
+ * (per 32 values of K one 128-byte line; hi + lo carry 22 significant bits).  Packed once per set of weights. */
 int rac_gemm_split_pack_fwd(const float *weight, void *image, int N, int K, float scale, void *stream);
 
 /* AdaptiveMixing.out_proj (nn.Linear(groups*128*64 -> 256), models/racformer_transformer.py:566,606) as a hand-written
  * split-K GEMM on the f16 matrix cores at fp32-GEMM accuracy (three products hi*hi + hi*lo + lo*hi, fp32 accumulate):
  *   partials[s][m][n] = sum_{k in slice s} Z[m][k] * W[n][k]        (unscaled: the consumer applies both powers of two)
- *   z_image : device f16 line image [M][K/64][hi 64 | lo 64]   (rac_mixing_fwd's out_split)
- *   w_image : device f16 line image [N][K/64][hi 64 | lo 64]   (rac_gemm_split_pack_fwd)
- *   partials: device f32 [slices][M][N];  K % (64 * slices) == 0.  rac_add_ln_fwd sums the slices. */
+ *   z_image : device f16 line image [M][K/32][hi 32 | lo 32]   (rac_mixing_fwd's out_split)
+ *   w_image : device f16 line image [N][K/32][hi 32 | lo 32]   (rac_gemm_split_pack_fwd)
+ *   partials: device f32 [slices][M][N];  K % (32 * slices) == 0.  rac_add_ln_fwd sums the slices. */
 int rac_outproj_fwd(const void *z_image, const void *w_image, float *partials, int M, int N, int K, int slices, void *stream);
 
 /* The temporal-fusion convolution of RadarBEVTemporalEncoder (3x3, stride 1, pad 1, Cin -> 256; the 193-GFLOP

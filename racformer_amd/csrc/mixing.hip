@@ -32,7 +32,7 @@ struct MixArgs {
     const float *x;       // [items_q, G, P, 64]
     const float *params;  // row q at params + q*ld_params: per group [64*64 | 128*P]
     float *out;           // [items_q, G, 128, 64] (may be null when out_split is given)
-    _Float16 *out_split;  // optional: f16 [items_q, G*128, hi 64 | lo 64] = the line image of out * split_scale (rac_outproj_fwd's A operand)
+    _Float16 *out_split;  // optional: f16 [items_q, G*256, hi 32 | lo 32] = the line image of out * split_scale (rac_outproj_fwd's A operand)
     int nq, G, P, ld_params;
     float eps, split_scale;
     float param_scale;    // every generated parameter is multiplied by this on load (the split GEMM's power-of-two alpha)
@@ -66,9 +66,9 @@ __device__ __forceinline__ void mix_write_out(const MixArgs &a, const float *sO,
             *reinterpret_cast<rac_f4 *>(go + i * 4) = *reinterpret_cast<const rac_f4 *>(sO + i * 4);
     }
     if (a.out_split) {
-        // A operand of out_proj as a 3-product split GEMM on the f16 matrix cores (rac_outproj_fwd): per 64 values of K one
-        // 256-byte line [hi 64 | lo 64] of out * split_scale.  K = (g, out point, channel), so the item's 128 out points
-        // are 128 consecutive lines: 32 KB contiguous per item, every value stored once.
+        // A operand of out_proj as a 3-product split GEMM on the f16 matrix cores (rac_outproj_fwd): per 32 values of K one
+        // 128-byte line [hi 32 | lo 32] of out * split_scale.  K = (g, out point, channel), so the item's 128 out points
+        // are 256 consecutive lines: 32 KB contiguous per item, every value stored once.
         _Float16 *go = a.out_split + ((size_t)q * a.G + g) * (size_t)(MIX_OUT * 2 * MIX_C);
         for (int i = tid; i < MIX_OUT * MIX_C / 4; i += 256) {
             const rac_f4 v = *reinterpret_cast<const rac_f4 *>(sO + i * 4);
@@ -77,10 +77,10 @@ __device__ __forceinline__ void mix_write_out(const MixArgs &a, const float *sO,
             rac_split_f16(v.y * a.split_scale, hi.y, lo.y);
             rac_split_f16(v.z * a.split_scale, hi.z, lo.z);
             rac_split_f16(v.w * a.split_scale, hi.w, lo.w);
-            const int o = i >> 4, c4 = i & 15;
-            _Float16 *dst = go + o * (2 * MIX_C) + c4 * 4;
+            const int o = i >> 4, c = (i & 15) * 4;
+            _Float16 *dst = go + (o * 2 + (c >> 5)) * 64 + (c & 31);
             *reinterpret_cast<rac_h4 *>(dst) = hi;
-            *reinterpret_cast<rac_h4 *>(dst + MIX_C) = lo;
+            *reinterpret_cast<rac_h4 *>(dst + 32) = lo;
         }
     }
 }

@@ -149,7 +149,7 @@ def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range, box_table=None):
 def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5, split=False, param_scale=1.0, f16x3=False):
     """x [B,Q,G,P,64] (contiguous), params [B,Q,G*(64*64+128*P)] (unit inner stride) ->
     relu(LN(S @ relu(LN(x @ M)))) as [B,Q,G*128*64], ready for out_proj.
-    ``split=True``: instead returns the f16 line image [B*Q, G*128, hi 64 | lo 64] of the same values * SPLIT_ACT_SCALE
+    ``split=True``: instead returns the f16 line image [B*Q, G*256, hi 32 | lo 32] of the same values * SPLIT_ACT_SCALE
     (A operand of rac_outproj_fwd: every value stored once as hi + lo).
     ``param_scale``: factor applied to every parameter on load (the power-of-two alpha of a split generator GEMM).
     ``f16x3``: run the two products as 3-product split-precision f16 MFMAs (RAC_MIX_F16X3) instead of f32-input MFMAs."""
@@ -160,7 +160,7 @@ def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5, split
     width = G * (C * C + out_points * P)
     p_par, ld_par = _rows(params, width, "mixing_fused(params)")
     if split:
-        out = torch.empty(B * Q, G * out_points, 2 * C, device=x.device, dtype=torch.float16)
+        out = torch.empty(B * Q, G * out_points * C // 32, 64, device=x.device, dtype=torch.float16)
     else:
         out = torch.empty(B, Q, G * out_points * C, device=x.device, dtype=torch.float32)
     ev = _lib.timer.record("mixing_fwd") if _lib.timer is not None else None
@@ -523,35 +523,35 @@ def rowgemm_launch(descs, rows):
 
 # ------------------------------------------------------------------------------------------- split-precision GEMM
 def pack_gemm_split_weight(weight):
-    """nn.Linear weight [N, K] fp32 (device) -> (f16 line image [N, K/64, 128] = [hi 64 | lo 64] of weight * 2^s, alpha) for
+    """nn.Linear weight [N, K] fp32 (device) -> (f16 line image [N, K/32, 64] = [hi 32 | lo 32] of weight * 2^s, alpha) for
     rac_outproj_fwd: alpha = 2^-s / SPLIT_ACT_SCALE undoes the weight's and the activation image's power-of-two scalings.
-    (None, None) if f16 cannot hold the weights or K is not a multiple of 64."""
+    (None, None) if f16 cannot hold the weights or K is not a multiple of 32."""
     import math
     w = weight.detach().float().contiguous()
     N, K = w.shape
     amax = float(w.abs().max())
-    if K % 64 != 0 or not w.is_cuda or not (amax > 0.0) or amax != amax or amax == float("inf"):
+    if K % 32 != 0 or not w.is_cuda or not (amax > 0.0) or amax != amax or amax == float("inf"):
         return None, None
     s = 13 - math.frexp(amax)[1] + 1          # amax * 2^s in [2^13, 2^14)
-    img = torch.empty(N, K // 64, 128, device=w.device, dtype=torch.float16)
+    img = torch.empty(N, K // 32, 64, device=w.device, dtype=torch.float16)
     _lib.check(_lib.lib().rac_gemm_split_pack_fwd(_lib.ptr(w), _lib.ptr(img), N, K, float(2.0 ** s), _lib.stream_ptr()),
                "rac_gemm_split_pack_fwd")
     return img, 2.0 ** (-s) / SPLIT_ACT_SCALE
 
 
 def outproj_fused(z_image, w_image, slices):
-    """z_image f16 [M, K/64, 128], w_image f16 [N, K/64, 128] -> fp32 partials [slices, M, N] (unscaled), one launch."""
+    """z_image f16 [M, K/32, 64], w_image f16 [N, K/32, 64] -> fp32 partials [slices, M, N] (unscaled), one launch."""
     _lib.require_gpu(z_image, w_image, what="outproj_fused")
     M, lines, _ = z_image.shape
     N = w_image.shape[0]
-    if z_image.dtype != torch.float16 or w_image.dtype != torch.float16 or tuple(w_image.shape[1:]) != (lines, 128) \
-            or z_image.shape[2] != 128 or lines % slices != 0:
+    if z_image.dtype != torch.float16 or w_image.dtype != torch.float16 or tuple(w_image.shape[1:]) != (lines, 64) \
+            or z_image.shape[2] != 64 or lines % slices != 0:
         raise RuntimeError("outproj_fused: operand images do not match")
     out = torch.empty(slices, M, N, device=z_image.device, dtype=torch.float32)
     ev = _lib.timer.record("mixing_out_proj_gemm") if _lib.timer is not None else None
     if ev:
         ev[0].record()
-    rc = _lib.lib().rac_outproj_fwd(_lib.ptr(z_image), _lib.ptr(w_image), _lib.ptr(out), M, N, lines * 64, slices, _lib.stream_ptr())
+    rc = _lib.lib().rac_outproj_fwd(_lib.ptr(z_image), _lib.ptr(w_image), _lib.ptr(out), M, N, lines * 32, slices, _lib.stream_ptr())
     if ev:
         ev[1].record()
     _lib.check(rc, "rac_outproj_fwd")

@@ -688,7 +688,7 @@ class AdaptiveMixing(nn.Module):
     SPLIT_SLICE = SPLIT_SLICE   # K slice of out_proj's split-K batches; fixed by rac_mixing_fwd's out_split layout
 
     def split_packs(self, act_bound=None):
-        """-> dict(gen_w [N,3K+64] f16, gen_alpha, out_w (line image [256, K/64, 128] f16), out_alpha, out_slices), or {} if f16 cannot hold the
+        """-> dict(gen_w [N,3K+64] f16, gen_alpha, out_w (line image [256, K/32, 64] f16), out_alpha, out_slices), or {} if f16 cannot hold the
         operands: a weight or bias overflows, |activation| bound * SPLIT_ACT_SCALE >= 6e4, or the generated
         parameters -- bounded by max_row ||W_row||_1 * act_bound + max|bias| -- could reach the f16 range that
         rac_mixing_fwd's RAC_MIX_F16X3 mode needs for S.  (One-off host reads; the result is cached.)"""
@@ -704,7 +704,7 @@ class AdaptiveMixing(nn.Module):
         gen_w, gen_alpha = split_weight_f16(gen.weight, gen.bias)
         if gen_w is None:
             return {}
-        ow, out_alpha = pack_gemm_split_weight(w)        # line image [N, K/64, hi 64 | lo 64] for rac_outproj_fwd
+        ow, out_alpha = pack_gemm_split_weight(w)        # line image [N, K/32, hi 32 | lo 32] for rac_outproj_fwd
         if ow is None:
             return {}
         return dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow, out_alpha=out_alpha, out_slices=K // self.SPLIT_SLICE)

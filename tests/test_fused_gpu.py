@@ -202,12 +202,12 @@ def test_split_precision_operands_and_gemms():
         params = mix.parameter_generator(q)
         z = mixing_fused(x, params, 96, 4, 128)
         z16 = mixing_fused(x, params, 96, 4, 128, split=True)
-        assert tuple(z16.shape) == (64, 4 * 128, 128)                     # line image: [hi 64 | lo 64] per out point
-        zh, zl = z16.float().view(64, 512, 2, 64).unbind(2)
+        assert tuple(z16.shape) == (64, 4 * 256, 64)                      # line image: [hi 32 | lo 32] per 32 values of K
+        zh, zl = z16.float().view(64, 1024, 2, 32).unbind(2)
         rec = ((zh.double() + zl.double()) / SPLIT_ACT_SCALE).reshape(64, -1)
         assert (rec - z.view(64, -1).double()).abs().max().item() <= 2.0 ** -21 * z.abs().max().item()
         packs = mix.split_packs()
-        wh, wl = packs["out_w"].float().view(256, 512, 2, 64).unbind(2)    # the packed weight image holds W * 2^s as hi + lo
+        wh, wl = packs["out_w"].float().view(256, 1024, 2, 32).unbind(2)   # the packed weight image holds W * 2^s as hi + lo
         wrec = (wh.double() + wl.double()).reshape(256, -1) * (packs["out_alpha"] * SPLIT_ACT_SCALE)
         assert (wrec - mix.out_proj.weight.double()).abs().max().item() <= 2.0 ** -21 * mix.out_proj.weight.abs().max().item()
         part = outproj_fused(z16, packs["out_w"], packs["out_slices"]) * packs["out_alpha"]
@@ -219,7 +219,8 @@ def test_split_precision_operands_and_gemms():
     assert mix.split_packs(act_bound=1e5) == {}     # operands outside the f16 range: the caller keeps the fp32 GEMMs
 
 
-@pytest.mark.parametrize("M,N,K,S", [(900, 256, 32768, 16), (131, 256, 4096, 2), (7, 100, 1024, 4), (128, 128, 64, 1)])
+@pytest.mark.parametrize("M,N,K,S", [(900, 256, 32768, 16), (131, 256, 4096, 2), (7, 100, 1024, 4), (128, 128, 64, 1), (128, 128, 32, 1),
+                                     (200, 130, 96, 1)])
 def test_outproj_kernel_vs_float64(M, N, K, S):
     """rac_outproj_fwd (hand-written split-K GEMM, LDS-DMA staging, source-side swizzle) against a float64 GEMM of the values
     its operand images hold: asymmetric integer-free random operands, ragged M / N (tile edges), every slice checked."""
@@ -228,10 +229,10 @@ def test_outproj_kernel_vs_float64(M, N, K, S):
     z = torch.randn(M, K, generator=g).to(DEV)
     w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
 
-    def image(t):       # [R, K] f32 -> line image [R, K/64, hi 64 | lo 64] f16 and the f64 values it represents
+    def image(t):       # [R, K] f32 -> line image [R, K/32, hi 32 | lo 32] f16 and the f64 values it represents
         hi = t.to(torch.float16)
         lo = (t - hi.float()).to(torch.float16)
-        img = torch.stack([hi.view(-1, K // 64, 64), lo.view(-1, K // 64, 64)], dim=2).reshape(-1, K // 64, 128).contiguous()
+        img = torch.stack([hi.view(-1, K // 32, 32), lo.view(-1, K // 32, 32)], dim=2).reshape(-1, K // 32, 64).contiguous()
         return img, hi.double() + lo.double()
 
     zi, zv = image(z * 16.0)

@@ -34,6 +34,7 @@
  *   rac_decode_fwd    <- NMSFreeCoder.decode_single + get_bboxes, models/bbox/coders/nms_free_coder.py:37-88,
  *                        models/racformer_head.py:488-507
  *   rac_outproj_fwd / rac_gemm_split_pack_fwd <- AdaptiveMixing.out_proj (nn.Linear 32768 -> 256), models/racformer_transformer.py:566,606
+ *   rac_generator_fwd <- AdaptiveMixing.parameter_generator (nn.Linear 256 -> 65536), models/racformer_transformer.py:565,589
  *   rac_rowgemm_fwd   <- nn.Linear + its preceding add / LayerNorm / ReLU groups, models/racformer_transformer.py:170-177, 243-269
  *   rac_gru_gate_fwd / rac_upsample2x_fwd <- ConvGRUCell.forward's element-wise tail, nn.Upsample
  *                        models/racformer_transformer.py:705-720, :633-636
@@ -225,6 +226,15 @@ int rac_gemm_split_pack_fwd(const float *weight, void *image, int N, int K, floa
  *   partials: device f32 [slices][M][N];  K % (32 * slices) == 0.  rac_add_ln_fwd sums the slices. */
 int rac_outproj_fwd(const void *z_image, const void *w_image, float *partials, int M, int N, int K, int slices, void *stream);
 
+/* AdaptiveMixing.parameter_generator (nn.Linear(256 -> groups*(64*64 + 128*in_points)), models/racformer_transformer.py:565,589)
+ * on the same hand-written kernel:  out[m][n] = alpha * sum_k X[m][k] * W[n][k] + bias[n]   (alpha undoes the two powers of two
+ * of the images).  One workgroup per 256 features walks all rows: the weights cross the fabric once.
+ *   x_image : device f16 line image [M][K/32][hi 32 | lo 32]   (rac_rowgemm_fwd's split_out, split_layout = RAC_SPLIT_LINES)
+ *   w_image : device f16 line image [N][K/32][hi 32 | lo 32]   (rac_gemm_split_pack_fwd);  bias device f32 [N] or NULL
+ *   out     : device f32, row m at out + m*ld_out;  K % 32 == 0, N % 4 == 0, ld_out % 4 == 0 */
+int rac_generator_fwd(const void *x_image, const void *w_image, const float *bias, float alpha, float *out, long ld_out, int M,
+                      int N, int K, void *stream);
+
 /* The temporal-fusion convolution of RadarBEVTemporalEncoder (3x3, stride 1, pad 1, Cin -> 256; the 193-GFLOP
  * nn.Conv2d of models/racformer_transformer.py:631,655) as an implicit GEMM on the f16 matrix cores with
  * hi/lo-split operands (3 products, fp32 accumulate: fp32-convolution accuracy).  Three calls:
@@ -267,7 +277,8 @@ int rac_upsample2x_fwd(const float *src, float *dst, int64_t planes, int h, int 
  * Up to RAC_ROWGEMM_MAX_BATCH independent GEMMs over the same `rows` share the launch (descs: HOST array). */
 #define RAC_ROWGEMM_MAX_BATCH 3
 enum {
-    RAC_SPLIT_KCAT = 0     /* split_out rows [hi 256 | hi 256 | lo 256 | pad]: A operand of a K-concatenated library GEMM */
+    RAC_SPLIT_KCAT = 0,    /* split_out rows [hi 256 | hi 256 | lo 256 | pad]: A operand of a K-concatenated library GEMM */
+    RAC_SPLIT_LINES = 1    /* split_out rows [8 lines][hi 32 | lo 32] (1 KB): X image of rac_generator_fwd */
 };
 typedef struct {
     const float *a;

@@ -39,6 +39,7 @@ SIGNATURES = {
     "rac_rowgemm_fwd": (_i, [_vp, _i, _i, _vp]),
     "rac_gemm_split_pack_fwd": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "rac_outproj_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rac_generator_fwd": (_i, [_vp, _vp, _vp, _f, _vp, ctypes.c_long, _i, _i, _i, _vp]),
     "rac_gru_gate_fwd": (_i, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
     "rac_upsample2x_fwd": (_i, [_vp, _vp, ctypes.c_int64, _i, _i, _vp]),
     "rac_absmax_fwd": (_i, [_vp, _vp, _i, _f, _vp, _vp]),

@@ -1,101 +1,137 @@
 // gemm_split.hip -- split-precision GEMMs of AdaptiveMixing on the f16 matrix cores (gfx950), hand-written:
-//   rac_outproj_fwd : out_proj, nn.Linear(32768 -> 256) over 900 queries (models/racformer_transformer.py:566,606), as
-//                     a split-K GEMM  partial[s] = Z[:, slice s] @ W[:, slice s]^T
+//   rac_outproj_fwd  : out_proj, nn.Linear(32768 -> 256) over 900 queries (models/racformer_transformer.py:566,606), as a
+//                      split-K GEMM  partial[s] = Z[:, slice s] @ W[:, slice s]^T
+//   rac_generator_fwd: parameter_generator, nn.Linear(256 -> 65536) (models/racformer_transformer.py:565,589)
 //
 // Arithmetic (same as conv3x3.hip): every operand is v * 2^e = hi + lo (two f16, 22 significant bits); the three
 // leading products lo*hi + hi*lo + hi*hi are accumulated in fp32 by v_mfma_f32_16x16x32_f16 -- the dropped lo*lo term
-// is 2^-22 relative, the result matches an fp32 GEMM to fp32 rounding.  Both powers of two are undone by the consumer
-// (rac_add_ln_fwd's a_scale), so partials leave the kernel unscaled.
+// is 2^-22 relative, the result matches an fp32 GEMM to fp32 rounding.
 //
-// Operand images (one format for A and B): row r, per 32 values of K one 128-byte line [hi 32 | lo 32] f16.
-//   Z image  [M][K/32][hi 32 | lo 32]  written by rac_mixing_fwd (out_split)          118 MB for 900 x 32768
-//   W image  [N][K/32][hi 32 | lo 32]  packed once from the nn.Linear weight [N][K]   33.5 MB
+// Operand images (one format for both operands): row r, per 32 values of K one 128-byte line [hi 32 | lo 32] f16.
+//   X image  [M][K/32][hi 32 | lo 32]  activations: written by the producing kernel (rac_mixing_fwd's out_split: 118 MB for
+//                                       900 x 32768; rac_rowgemm_fwd's split_out: 0.9 MB for 900 x 256)
+//   W image  [N][K/32][hi 32 | lo 32]  packed once from the nn.Linear weight [N][K]
 // Compared with the K-concatenated [hi | hi | lo] x [hi | lo | hi] operands a library GEMM needs, each value is stored
-// once (4 B instead of 6 B): 59 MB less written by the mixing kernel and 76 MB less read here, per layer.
+// once (4 B instead of 6 B).
 //
-// Workgroup = 512 threads: 4 multiplying waves (2 x 2, 64 x 64 = 4 x 4 MFMA tiles each) + 4 loader waves; tile = 128 rows x
-// 128 columns x one K slice.  K loop in steps of 32: per step 128 + 128 lines of 128 B = 32 KB go global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, no ds_write) into a ring of four stages (128 KB), three steps ahead of
-// the MFMAs (counted vmcnt, one barrier per step).  LDS-DMA writes a wave-instruction's 1 KB linearly (8 lines), so bank
-// conflicts are avoided on the SOURCE side: LDS slot p of line r receives the line's 16-byte chunk p ^ ((r >> 1) & 7),
-// and the fragment reads apply the same XOR -- every ds_read_b128 is conflict-free.
-// Grid = row tiles x column tiles x K slices = 8 x 2 x 16 = 256 workgroups for out_proj: one per CU.
+// Workgroup = 768 threads = 8 multiplying waves + 4 loader waves; tile = 256 output features (W rows) x up to 128 rows of
+// X, K in steps of 32.  The multiplying waves (4 along the features x 2 along the rows, 64 x 64 = 4 x 4 MFMA tiles each,
+// two per SIMD) never issue a vector-memory instruction; the loader waves move each step's 256 + 128 lines (48 KB) global
+// -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) into a ring of three stages (144 KB), two
+// steps ahead of the MFMAs (counted vmcnt, one barrier per step).  Why this shape: an LDS-DMA piece costs its wave 60-185
+// issue cycles and a CU takes in at most ~68 GB/s this way (MI355X_MICROARCH.md); a 128 x 128 tile with the loads in the
+// multiplying waves ran out_proj at 2.2 us per 64-deep step (70 us per launch, as hipBLASLt), with loader waves at 50 us;
+// 48 KB for 96 MFMAs per SIMD balances the intake (0.7 us) with the matrix pipe (0.73 us).
+// LDS-DMA writes a wave-instruction's 1 KB linearly (8 lines), so bank conflicts are avoided on the SOURCE side: LDS slot
+// p of line r receives the line's 16-byte chunk p ^ ((r >> 1) & 7), and the fragment reads apply the same XOR -- every
+// ds_read_b128 is conflict-free.
+// The MFMA's A operand is W (features), its B operand X (rows): a lane's four accumulator registers are four consecutive
+// FEATURES of one row, i.e. one 16-byte store.
+// The rows of X are cut into ceil(M/128) tiles of whole 16-row MFMA tiles, as equal as possible (900 rows: seven tiles of
+// 112 rows and one of 116), and MFMA tiles past a row tile's end are skipped: no work on padding.
+// A workgroup walks `tiles_per_wg` consecutive tiles (row tile fastest) with the ring running across tile boundaries: the
+// loaders fetch the next tile while the multiplying waves store the finished one.  Workgroups b, b + 8, ... share an XCD
+// (round-robin dispatch) and take consecutive tile ranges, so tiles that share W rows pull them through one L2.
 #include "rac_common.h"
 
 typedef _Float16 gs_h8 __attribute__((ext_vector_type(8)));
 typedef float gs_f4 __attribute__((ext_vector_type(4)));
 
-#define GS_TM 128
-#define GS_TN 128
+#define GS_TW 256                          /* W rows (output features) per tile */
+#define GS_TX 128                          /* X rows per tile (at most) */
 #define GS_LINE 128                        /* bytes per row and K step of 32: [hi 32 | lo 32] f16 */
-#define GS_STAGE (2 * GS_TM * GS_LINE)     /* 32 KB: A tile then B tile */
-#define GS_STAGES 4
-#define GS_PIECES 32                       /* 1 KB LDS-DMA pieces per stage: 16 for A, 16 for B; 8 per loader wave */
+#define GS_STAGE ((GS_TW + GS_TX) * GS_LINE) /* 48 KB: W lines then X lines */
+#define GS_STAGES 3
+#define GS_PIECES_PER_LOADER 12            /* 48 one-KB LDS-DMA pieces per stage, four loader waves */
 
 struct GemmSplitArgs {
-    const char *a;    // A image
-    const char *b;    // B image
-    float *out;       // [S][M][N] partial products (unscaled)
-    int M, N, K;      // K = full reduction length (multiple of 32 * slices)
-    int slices;       // split-K factor; blockIdx.z
+    const char *x;      // X image
+    const char *w;      // W image
+    float *out;         // partial mode: [slices][M][N] raw products;  affine mode: [M][ld_out] = alpha * acc + bias[n]
+    const float *bias;  // affine mode only (may be null)
+    float alpha;
+    int M, N, K;        // K = full reduction length (multiple of 32 * slices)
+    int slices;         // split-K factor (1 in affine mode)
+    int tiles_x, tiles_w;   // row tiles of X, feature tiles of W
+    int m16;            // ceil(M / 16)
+    int tiles_per_wg;
+    int affine;
+    long ld_out;
 };
 
-// One 128 x 128 x (K / slices) tile.  512 threads: waves 0-3 multiply (2 x 2, 64 x 64 each), waves 4-7 only load.
-//   loader wave, step s : issue the 8 pieces of K step s+3 into ring stage (s+3)%4, wait until all but the youngest 16
-//                         pieces (steps s+2, s+3) have landed -> step s+1 is complete, barrier
-//   compute wave, step s: 16 fragment reads + 48 MFMAs on stage s%4, wait for its own LDS reads, barrier
-// The barrier at the end of step s therefore publishes stage (s+1)%4 to the readers and frees stage s%4 for the loaders
-// (they write it in step s+1).  The multiplying waves never issue a vector-memory instruction: an LDS-DMA piece costs its
-// wave 60-185 issue cycles (MI355X_MICROARCH.md), 16 of them per K step in front of the MFMAs made the first version of
-// this kernel run at 2.2 us per 64-deep step against 0.7 us of MFMA time.
-__global__ __launch_bounds__(512, 1) void gemm_split_kernel(const GemmSplitArgs g)
+// rows [begin, end) of X row tile i: whole 16-row MFMA tiles, as equal as possible
+__device__ __forceinline__ void gs_row_tile(const GemmSplitArgs &g, int i, int &begin, int &end)
+{
+    begin = 16 * ((i * g.m16) / g.tiles_x);
+    end = 16 * (((i + 1) * g.m16) / g.tiles_x);
+    end = end < g.M ? end : g.M;
+}
+
+__global__ __launch_bounds__(768, 1) void gemm_split_kernel(const GemmSplitArgs g)
 {
     extern __shared__ char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int row0 = blockIdx.x * GS_TM, col0 = blockIdx.y * GS_TN;
+    // XCD-major workgroup order (speed only: any placement computes the same tiles)
+    const int nwg = gridDim.x;
+    const int wg = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int ksteps = g.K / 32 / g.slices;
+    const int ntiles = g.tiles_x * g.tiles_w * g.slices;
+    const int t_begin = wg * g.tiles_per_wg;
+    int my_tiles = ntiles - t_begin;
+    my_tiles = my_tiles < g.tiles_per_wg ? my_tiles : g.tiles_per_wg;
+    if (my_tiles <= 0)
+        return;
+    const int gsteps = my_tiles * ksteps;                          // K steps of all my tiles, one continuous sequence
     const size_t line_stride = (size_t)(g.K / 32) * GS_LINE;     // bytes between consecutive rows of an image
-    const size_t k0 = (size_t)blockIdx.z * ksteps * GS_LINE;      // byte offset of this slice inside a row
 
-    if (wave >= 4) {
+    if (wave >= 8) {
         // ---------------------------------------------------------------- loader waves
-        // piece p of a stage = 8 lines (rows 8p .. 8p+7 of the A tile for p < 16, of the B tile for p >= 16); lane: line
-        // lane >> 3, LDS slot lane & 7, which receives the line's 16-byte chunk slot ^ ((row >> 1) & 7)
-        const int lw = wave - 4;
-        const char *src[8];
+        // piece p of a stage = 8 lines: W rows 8p .. 8p+7 of the tile for p < 32, X rows 8(p-32) .. for p >= 32.  Lane: line
+        // lane >> 3 of the eight, LDS slot lane & 7, which receives the line's 16-byte chunk slot ^ ((row >> 1) & 7).
+        const int lw = wave - 8;
+        const char *src[GS_PIECES_PER_LOADER];
+        auto set_tile = [&](int t) {
+            const int xt = t % g.tiles_x, r2 = t / g.tiles_x, wt = r2 % g.tiles_w, slice = r2 / g.tiles_w;
+            int xb, xe;
+            gs_row_tile(g, xt, xb, xe);
+            const size_t k0 = (size_t)slice * ksteps * GS_LINE;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int p = lw + 4 * j;
-            const bool isb = p >= 16;
-            const int line = (p & 15) * 8 + (lane >> 3);
-            int r = (isb ? col0 : row0) + line;
-            const int lim = isb ? g.N : g.M;
-            r = r < lim ? r : lim - 1;             // lines past the edge re-read the last row; their results are not stored
-            src[j] = (isb ? g.b : g.a) + (size_t)r * line_stride + k0 + (size_t)(((lane & 7) ^ ((line >> 1) & 7)) * 16);
-        }
-        auto issue = [&](int ks) {
-            char *stage = lds + (ks & (GS_STAGES - 1)) * GS_STAGE;
+            for (int j = 0; j < GS_PIECES_PER_LOADER; ++j) {
+                const int p = lw + 4 * j;
+                const bool isx = p >= 32;
+                const int line = (p & 31) * 8 + (lane >> 3);
+                int r = isx ? xb + line : wt * GS_TW + line;
+                const int lim = isx ? xe : g.N;
+                r = r < lim ? r : lim - 1;         // lines past the edge re-read the last row; their results are not stored
+                src[j] = (isx ? g.x : g.w) + (size_t)r * line_stride + k0 + (size_t)(((lane & 7) ^ ((line >> 1) & 7)) * 16);
+            }
+        };
+        auto issue = [&](int gs) {
+            const int ks = gs % ksteps;
+            if (ks == 0)
+                set_tile(t_begin + gs / ksteps);
+            char *stage = lds + (gs % GS_STAGES) * GS_STAGE;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < GS_PIECES_PER_LOADER; ++j) {
                 const int p = lw + 4 * j;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + (size_t)ks * GS_LINE),
                                                  (__attribute__((address_space(3))) void *)(stage + p * 1024), 16, 0, 0);
             }
         };
-        // prologue: steps 0, 1, 2 in flight; step 0 must have landed before the first barrier
+        // prologue: steps 0 and 1 in flight; step 0 must have landed before the first barrier
         issue(0);
-        if (ksteps > 1) issue(1);
-        if (ksteps > 2) issue(2);
-        if (ksteps > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (ksteps > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (gsteps > 1) {
+            issue(1);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        for (int ks = 0; ks < ksteps; ++ks) {
-            if (ks + 3 < ksteps) {
-                issue(ks + 3);
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // steps ks+2, ks+3 may still be in flight
-            } else if (ks + 2 < ksteps) {
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // only step ks+2 behind ks+1
+        for (int gs = 0; gs < gsteps; ++gs) {
+            // stage (gs+2)%3 was read in step gs-1: free since the barrier that ended it
+            if (gs + 2 < gsteps) {
+                issue(gs + 2);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // all but step gs+2 landed: step gs+1 is complete
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -106,68 +142,90 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const GemmSplitArgs 
 
     // -------------------------------------------------------------------- multiplying waves
     const int li = lane & 15, lk = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    gs_f4 acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-            acc[m][n] = (gs_f4){0.f, 0.f, 0.f, 0.f};
-    // fragment addresses: line = tile row, chunk c (hi: lk, lo: 4 + lk) at slot c ^ ((row >> 1) & 7); tiles start at
+    const int ww = wave >> 1, wx = wave & 1;       // 4 along W (64 features each) x 2 along X (64 rows each)
+    // fragment addresses: line = tile row, chunk c (hi: lk, lo: 4 + lk) at slot c ^ ((row >> 1) & 7); MFMA tiles start at
     // multiples of 16, so (row >> 1) & 7 == (li >> 1) & 7 for every fragment row
     const int f = (li >> 1) & 7;
     const int ch = (lk ^ f) * 16, cl = ((4 + lk) ^ f) * 16;
-    int a_off[4], b_off[4];
+    int w_off[4], x_off[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        a_off[m] = (64 * wm + 16 * m + li) * GS_LINE;
-        b_off[m] = GS_TM * GS_LINE + (64 * wn + 16 * m + li) * GS_LINE;
+    for (int i = 0; i < 4; ++i) {
+        w_off[i] = (64 * ww + 16 * i + li) * GS_LINE;
+        x_off[i] = GS_TW * GS_LINE + (64 * wx + 16 * i + li) * GS_LINE;
     }
-    __builtin_amdgcn_s_barrier();          // step 0 has landed
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const char *S = lds + (ks & (GS_STAGES - 1)) * GS_STAGE;
-        gs_h8 bh[4], bl[4];
+    gs_f4 acc[4][4];                                // [W tile][X tile]: rows = features, cols = X rows
+    __builtin_amdgcn_s_barrier();                   // step 0 has landed
+    int gs = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const int t = t_begin + ti;
+        const int xt = t % g.tiles_x, r2 = t / g.tiles_x, wt = r2 % g.tiles_w, slice = r2 / g.tiles_w;
+        int xb, xe;
+        gs_row_tile(g, xt, xb, xe);
+        // 16-row X tiles of this wave that hold real rows (wave-uniform)
+        int nx = (xe - xb - 64 * wx + 15) >> 4;
+        nx = nx < 0 ? 0 : (nx > 4 ? 4 : nx);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            bh[n] = *reinterpret_cast<const gs_h8 *>(S + b_off[n] + ch);
-            bl[n] = *reinterpret_cast<const gs_h8 *>(S + b_off[n] + cl);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = (gs_f4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < ksteps; ++ks, ++gs) {
+            const char *S = lds + (gs % GS_STAGES) * GS_STAGE;
+            gs_h8 wh[4], wl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wh[i] = *reinterpret_cast<const gs_h8 *>(S + w_off[i] + ch);
+                wl[i] = *reinterpret_cast<const gs_h8 *>(S + w_off[i] + cl);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nx) {
+                    const gs_h8 xh = *reinterpret_cast<const gs_h8 *>(S + x_off[j] + ch);
+                    const gs_h8 xl = *reinterpret_cast<const gs_h8 *>(S + x_off[j] + cl);
+                    // smallest terms first
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh, acc[i][j], 0, 0, 0);
+                }
+            }
+            // every fragment of this stage is in registers (the MFMAs consumed them): the loaders may overwrite it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
+        // epilogue (the loaders are already fetching the next tile): C/D layout col = li (X row), row = 4 * lk + r
+        // (feature): four consecutive features per lane = one 16-byte store
+        float *obase = g.affine ? g.out : g.out + (size_t)slice * g.M * g.N;
+        const long ld = g.affine ? g.ld_out : (long)g.N;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const gs_h8 ah = *reinterpret_cast<const gs_h8 *>(S + a_off[m] + ch);
-            const gs_h8 al = *reinterpret_cast<const gs_h8 *>(S + a_off[m] + cl);
-            // smallest terms first
+        for (int j = 0; j < 4; ++j) {
+            const int row = xb + 64 * wx + 16 * j + li;
+            if (j < nx && row < xe) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], acc[m][n], 0, 0, 0);
-        }
-        // every fragment of this stage is in registers (the MFMAs above consumed them): the loaders may overwrite it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // epilogue: C/D layout col = li, row = 4 * lk + r within a 16 x 16 tile
-    float *obase = g.out + (size_t)blockIdx.z * g.M * g.N;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + 64 * wm + 16 * m + 4 * lk + r;
-            if (row < g.M) {
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int col = col0 + 64 * wn + 16 * n + li;
-                    if (col < g.N)
-                        obase[(size_t)row * g.N + col] = acc[m][n][r];
+                for (int i = 0; i < 4; ++i) {
+                    const int n = wt * GS_TW + 64 * ww + 16 * i + 4 * lk;
+                    if (n + 3 < g.N) {
+                        gs_f4 v = acc[i][j];
+                        if (g.affine) {
+                            const gs_f4 b = g.bias ? *reinterpret_cast<const gs_f4 *>(g.bias + n) : (gs_f4){0.f, 0.f, 0.f, 0.f};
+                            v = v * g.alpha + b;
+                        }
+                        *reinterpret_cast<gs_f4 *>(obase + (size_t)row * ld + n) = v;
+                    } else {
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N)
+                                obase[(size_t)row * ld + n + r] = g.affine ? acc[i][j][r] * g.alpha + (g.bias ? g.bias[n + r] : 0.f)
+                                                                            : acc[i][j][r];
+                    }
                 }
             }
         }
+    }
 }
 
 // ---- weight packer: nn.Linear weight [N][K] f32 -> image [N][K/32][hi 32 | lo 32] f16 of weight * scale -------------------
@@ -199,6 +257,23 @@ extern "C" int rac_gemm_split_pack_fwd(const float *weight, void *image, int N, 
     return rac_launch_status("rac_gemm_split_pack_fwd");
 }
 
+static int gs_launch(GemmSplitArgs &g, int tiles_per_wg, hipStream_t st, const char *what)
+{
+    g.tiles_x = (g.M + GS_TX - 1) / GS_TX;
+    g.tiles_w = (g.N + GS_TW - 1) / GS_TW;
+    g.m16 = (g.M + 15) / 16;
+    g.tiles_per_wg = tiles_per_wg;
+    const int ntiles = g.tiles_x * g.tiles_w * g.slices;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GS_STAGES * GS_STAGE);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_split_kernel, dim3((ntiles + tiles_per_wg - 1) / tiles_per_wg), dim3(768), GS_STAGES * GS_STAGE, st, g);
+    return rac_launch_status(what);
+}
+
 extern "C" int rac_outproj_fwd(const void *z_image, const void *w_image, float *partials, int M, int N, int K, int slices,
                                void *stream)
 {
@@ -206,17 +281,24 @@ extern "C" int rac_outproj_fwd(const void *z_image, const void *w_image, float *
     RAC_CHECK_ARG(M >= 1 && N >= 1 && slices >= 1 && K >= 32 && K % (32 * slices) == 0,
                   "rac_outproj_fwd: M=%d N=%d K=%d slices=%d (K must be a multiple of 32 * slices)", M, N, K, slices);
     GemmSplitArgs g;
-    g.a = reinterpret_cast<const char *>(z_image);
-    g.b = reinterpret_cast<const char *>(w_image);
-    g.out = partials;
+    g.x = reinterpret_cast<const char *>(z_image);
+    g.w = reinterpret_cast<const char *>(w_image);
+    g.out = partials; g.bias = nullptr; g.alpha = 1.f; g.affine = 0; g.ld_out = N;
     g.M = M; g.N = N; g.K = K; g.slices = slices;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GS_STAGES * GS_STAGE);
-        attr_set = true;
-    }
-    const dim3 grid((M + GS_TM - 1) / GS_TM, (N + GS_TN - 1) / GS_TN, slices);
-    hipLaunchKernelGGL(gemm_split_kernel, grid, dim3(512), GS_STAGES * GS_STAGE, (hipStream_t)stream, g);
-    return rac_launch_status("rac_outproj_fwd");
+    return gs_launch(g, 1, (hipStream_t)stream, "rac_outproj_fwd");
+}
+
+extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const float *bias, float alpha, float *out, long ld_out,
+                                 int M, int N, int K, void *stream)
+{
+    RAC_CHECK_ARG(x_image && w_image && out, "rac_generator_fwd: null pointer");
+    RAC_CHECK_ARG(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && ld_out >= N && ld_out % 4 == 0 && N % 4 == 0,
+                  "rac_generator_fwd: M=%d N=%d K=%d ld_out=%ld (K %% 32, N %% 4, ld_out %% 4 must be 0)", M, N, K, ld_out);
+    GemmSplitArgs g;
+    g.x = reinterpret_cast<const char *>(x_image);
+    g.w = reinterpret_cast<const char *>(w_image);
+    g.out = out; g.bias = bias; g.alpha = alpha; g.affine = 1; g.ld_out = ld_out;
+    g.M = M; g.N = N; g.K = K; g.slices = 1;
+    // one workgroup per W tile walks all row tiles: its 256 W rows are fetched once and stay in its XCD's L2
+    return gs_launch(g, (M + GS_TX - 1) / GS_TX, (hipStream_t)stream, "rac_generator_fwd");
 }

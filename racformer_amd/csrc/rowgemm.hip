@@ -137,12 +137,20 @@ __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, flo
                         rac_split_f16(v.y * g.split_scale, hi.y, lo.y);
                         rac_split_f16(v.z * g.split_scale, hi.z, lo.z);
                         rac_split_f16(v.w * g.split_scale, hi.w, lo.w);
-                        _Float16 *dst = reinterpret_cast<_Float16 *>(g.split_out) + (size_t)row * (768 + g.split_pad);
-                        *reinterpret_cast<rac_h4 *>(dst + lane * 4) = hi;
-                        *reinterpret_cast<rac_h4 *>(dst + 256 + lane * 4) = hi;
-                        *reinterpret_cast<rac_h4 *>(dst + 512 + lane * 4) = lo;
-                        if (lane < g.split_pad)
-                            dst[768 + lane] = lane < 2 ? (_Float16)g.split_scale : (_Float16)0.f;
+                        if (g.split_layout == RAC_SPLIT_LINES) {
+                            // line image [8 lines][hi 32 | lo 32] (1 KB per row): the X operand of rac_generator_fwd; a lane's 4
+                            // columns sit in one line
+                            _Float16 *dst = reinterpret_cast<_Float16 *>(g.split_out) + (size_t)row * 512 + (lane >> 3) * 64 + (lane & 7) * 4;
+                            *reinterpret_cast<rac_h4 *>(dst) = hi;
+                            *reinterpret_cast<rac_h4 *>(dst + 32) = lo;
+                        } else {
+                            _Float16 *dst = reinterpret_cast<_Float16 *>(g.split_out) + (size_t)row * (768 + g.split_pad);
+                            *reinterpret_cast<rac_h4 *>(dst + lane * 4) = hi;
+                            *reinterpret_cast<rac_h4 *>(dst + 256 + lane * 4) = hi;
+                            *reinterpret_cast<rac_h4 *>(dst + 512 + lane * 4) = lo;
+                            if (lane < g.split_pad)
+                                dst[768 + lane] = lane < 2 ? (_Float16)g.split_scale : (_Float16)0.f;
+                        }
                     }
                 }
             }

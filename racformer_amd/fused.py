@@ -451,11 +451,12 @@ def _rows2d(t, what):
 
 
 def row_seg(a, num_partials=1, a_scale=1.0, bias0=None, residual=None, norm=None, relu=False, post=None, x_out=None,
-            split_out=None):
+            split_out=None, split_lines=False):
     """One 256-wide segment of a rowgemm's A operand (see rac_rowgemm_fwd):
     [relu](LN_norm(a_scale * sum_p a[p] + bias0 + residual)) [+ post]; ``a`` is [rows,256] (any row stride) or, with
     num_partials = S > 1, a contiguous [S, rows, 256].  ``x_out`` / ``split_out``: destinations for the finished rows
-    (fp32 [rows,256] / f16 [rows, 768 + SPLIT_BIAS_PAD])."""
+    (fp32 [rows,256] / f16 [rows, 768 + SPLIT_BIAS_PAD] for a K-concatenated library GEMM, or -- ``split_lines`` -- the f16
+    line image [rows, 8, hi 32 | lo 32] that ``generator_fused`` reads)."""
     g = _lib.RowSeg()
     keep = []
     if num_partials > 1:
@@ -485,11 +486,11 @@ def row_seg(a, num_partials=1, a_scale=1.0, bias0=None, residual=None, norm=None
         t, g.x_out, g.ld_xout = _rows2d(x_out, "x_out")
         keep.append(t)
     if split_out is not None:
-        width = 768 + SPLIT_BIAS_PAD
+        width = 512 if split_lines else 768 + SPLIT_BIAS_PAD
         if split_out.dtype != torch.float16 or not split_out.is_contiguous() or split_out.shape[-1] != width:
             raise RuntimeError(f"row_seg: split_out must be a contiguous f16 [rows, {width}] tensor")
         g.split_out, g.split_scale = ctypes.c_void_p(split_out.data_ptr()), SPLIT_ACT_SCALE
-        g.split_pad, g.split_layout = SPLIT_BIAS_PAD, 0
+        g.split_pad, g.split_layout = (0, 1) if split_lines else (SPLIT_BIAS_PAD, 0)
         keep.append(split_out)
     g._keep = keep
     return g
@@ -537,6 +538,26 @@ def pack_gemm_split_weight(weight):
     _lib.check(_lib.lib().rac_gemm_split_pack_fwd(_lib.ptr(w), _lib.ptr(img), N, K, float(2.0 ** s), _lib.stream_ptr()),
                "rac_gemm_split_pack_fwd")
     return img, 2.0 ** (-s) / SPLIT_ACT_SCALE
+
+
+def generator_fused(x_image, w_image, bias, alpha):
+    """x_image f16 [M, K/32 * 64] (row_seg(split_lines=True)), w_image f16 [N, K/32, 64] -> fp32 [M, N] = alpha * X @ W^T + bias
+    (rac_generator_fwd), one launch."""
+    _lib.require_gpu(x_image, w_image, what="generator_fused")
+    M = x_image.shape[0]
+    N, lines, _ = w_image.shape
+    if x_image.dtype != torch.float16 or w_image.dtype != torch.float16 or x_image.numel() != M * lines * 64 or w_image.shape[2] != 64:
+        raise RuntimeError("generator_fused: operand images do not match")
+    out = torch.empty(M, N, device=x_image.device, dtype=torch.float32)
+    ev = _lib.timer.record("mixing_generator_gemm") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_generator_fwd(_lib.ptr(x_image), _lib.ptr(w_image), _lib.ptr(bias) if bias is not None else None, float(alpha),
+                                      _lib.ptr(out), N, M, N, lines * 32, _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_generator_fwd")
+    return out
 
 
 def outproj_fused(z_image, w_image, slices):

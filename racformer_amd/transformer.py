@@ -26,7 +26,8 @@ import torch.nn.functional as F
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
 from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add_ln, bev_sampling_fused, box_prep,
-                    gru_gate_fused, layer_boundary_fused, mixing_fused, outproj_fused, pack_conv3x3_weight, pack_gemm_split_weight,
+                    generator_fused, gru_gate_fused, layer_boundary_fused, mixing_fused, outproj_fused, pack_conv3x3_weight,
+                    pack_gemm_split_weight,
                     pe_head, refine_fused, row_gemm,
                     row_seg, rowgemm_launch, sampling4d_fused, sasa_fused, split_weight_f16, upsample2x_fused)
 from .msda import msda_forward
@@ -685,7 +686,8 @@ class AdaptiveMixing(nn.Module):
     # ([hi | hi | lo] x [Whi | Wlo | Whi]); measured error vs float64 equals the fp32 GEMM's (tools/exp_splitgemm.py)
     # at 2.3x the fp32-MFMA GEMM rate.  Power-of-two scalings keep the lo parts out of f16 subnormals and are
     # undone exactly by the GEMM's alpha.
-    SPLIT_SLICE = SPLIT_SLICE   # K slice of out_proj's split-K batches; fixed by rac_mixing_fwd's out_split layout
+    SPLIT_SLICE = SPLIT_SLICE   # K slice of the fp32 library path's split-K batches
+    OUT_SLICE_K = 1024          # K per workgroup of rac_outproj_fwd: 8 row tiles x 32 slices = 256 workgroups at f8
 
     def split_packs(self, act_bound=None):
         """-> dict(gen_w [N,3K+64] f16, gen_alpha, out_w (line image [256, K/32, 64] f16), out_alpha, out_slices), or {} if f16 cannot hold the
@@ -695,7 +697,7 @@ class AdaptiveMixing(nn.Module):
         gen = self.parameter_generator
         w = self.out_proj.weight
         N, K = w.shape
-        if K % self.SPLIT_SLICE != 0:
+        if K % self.SPLIT_SLICE != 0 or K % self.OUT_SLICE_K != 0:
             return {}
         if act_bound is not None:
             param_bound = float(gen.weight.detach().abs().sum(dim=1).max()) * act_bound + float(gen.bias.detach().abs().max())
@@ -707,7 +709,11 @@ class AdaptiveMixing(nn.Module):
         ow, out_alpha = pack_gemm_split_weight(w)        # line image [N, K/32, hi 32 | lo 32] for rac_outproj_fwd
         if ow is None:
             return {}
-        return dict(gen_w=gen_w, gen_alpha=gen_alpha, out_w=ow, out_alpha=out_alpha, out_slices=K // self.SPLIT_SLICE)
+        gimg, gimg_alpha = pack_gemm_split_weight(gen.weight)      # line image [65536, 8, hi 32 | lo 32] for rac_generator_fwd
+        if gimg is None:
+            return {}
+        return dict(gen_w=gen_w, gen_alpha=gen_alpha, gen_img=gimg, gen_img_alpha=gimg_alpha, out_w=ow, out_alpha=out_alpha,
+                    out_slices=K // self.OUT_SLICE_K)
 
     def out_proj_partials(self, x, query, out_proj_split, params=None, packs=None, query_split=None):
         """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
@@ -722,10 +728,15 @@ class AdaptiveMixing(nn.Module):
         split = bool(packs) and query_split is not None
         params_scaled = False
         if params is None:
-            ev = timer.record("mixing_generator_gemm") if timer is not None else None
+            own = split and query_split.shape[-1] == 2 * self.query_dim
+            ev = timer.record("mixing_generator_gemm") if timer is not None and not own else None
             if ev:
                 ev[0].record()
-            if split:
+            if own:
+                # line image: the hand-written split-precision GEMM (bias and alpha in its epilogue; timed inside)
+                params = generator_fused(query_split, packs["gen_img"], self.parameter_generator.bias,
+                                         packs["gen_img_alpha"]).view(B, Q, -1)
+            elif split:
                 # bias rides in the K-concatenated operands; alpha (a power of two) is applied by the mixing kernel
                 params = torch.mm(query_split, packs["gen_w"].t(), out_dtype=torch.float32).view(B, Q, -1)
                 params_scaled = True
@@ -826,6 +837,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # producer's normalisation runs as the prologue of its consumer GEMM): 21 launches per layer instead of ~50.
         # False: library GEMMs + rac_add_ln_fwd launches (forward_fused_chain).
         self.rowgemm = True
+        # parameter generator on the hand-written split-precision GEMM (rac_generator_fwd); False: hipBLASLt over K-concatenated images
+        self.own_generator = True
         # ((next layer index, box pointer, shape, version), pe_head output, box table, the box tensor) handed from a layer's
         # boundary launch to the next call; the decoder clears it before layer 0, and it is only honoured for the matching
         # layer index and (live, unmodified) tensor
@@ -870,9 +883,11 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
              2.0 * Qn * G_ * (Pin * C_ * C_ + 128 * Pin * C_),
              2.0 * Qn * G_ * (6 * 96 * C_ * C_ + 3 * 128 * 96 * C_) if split else 2.0 * Qn * G_ * (96 * C_ * C_ + 128 * 96 * C_),
              16 if split else 32),
-            ("mixing_generator_gemm", "parameter_generator GEMM (hipBLASLt f16, K-concatenated hi/lo operands)" if split
+            ("mixing_generator_gemm", ("gemm_split_kernel (hand-written, 3 f16 products, loader waves + LDS-DMA ring)" if self.own_generator
+                                       else "parameter_generator GEMM (hipBLASLt f16, K-concatenated hi/lo operands)") if split
              else "parameter_generator GEMM (rocBLAS fp32)",
-             2.0 * Qn * E * gen_cols, 2.0 * Qn * gen_cols * ((3 * E + 64) if split else E), 16 if split else 32),
+             2.0 * Qn * E * gen_cols, 2.0 * Qn * gen_cols * ((3 * E + (0 if self.own_generator else 64)) if split else E),
+             16 if split else 32),
             ("mixing_out_proj_gemm", "gemm_split_kernel (hand-written split-K GEMM, 3 f16 products, LDS-DMA staging)" if split
              else "out_proj split-K batched GEMM (rocBLAS fp32)",
              2.0 * Qn * (G_ * 128 * C_) * E, 2.0 * Qn * (G_ * 128 * C_) * E * (3 if split else 1), 16 if split else 32),
@@ -989,9 +1004,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         rowgemm_launch([row_gemm([row_seg(o)], p.out_proj.weight, p.out_proj.bias, attn)], n)
         # x1 = norm1(x + attn) (+ its f16 image for the generator GEMM);  the eleven Linears of the three sampling modules
         x1 = new(B, Q, E)
-        x1_split = torch.empty(n, 3 * E + SPLIT_BIAS_PAD, device=dev, dtype=torch.float16) if packs else None
+        own_gen = bool(packs) and self.own_generator
+        x1_split = torch.empty(n, 2 * E if own_gen else 3 * E + SPLIT_BIAS_PAD, device=dev, dtype=torch.float16) if packs else None
         wide = new(B, Q, prepared["wide_w"].shape[0])
-        rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split)],
+        rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split, split_lines=own_gen)],
                                  prepared["wide_w"], prepared["wide_b"], wide)], n)
         lin = wide.split(prepared["wide_widths"], dim=-1)
         rb, lb = self.sampling_radar_bev, self.sampling_lss_bev

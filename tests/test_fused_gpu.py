@@ -211,7 +211,7 @@ def test_split_precision_operands_and_gemms():
         wrec = (wh.double() + wl.double()).reshape(256, -1) * (packs["out_alpha"] * SPLIT_ACT_SCALE)
         assert (wrec - mix.out_proj.weight.double()).abs().max().item() <= 2.0 ** -21 * mix.out_proj.weight.abs().max().item()
         part = outproj_fused(z16, packs["out_w"], packs["out_slices"]) * packs["out_alpha"]
-        assert tuple(part.shape) == (16, 64, 256)
+        assert tuple(part.shape) == (32, 64, 256)
         want = z.view(64, -1).double() @ mix.out_proj.weight.double().t()
         e_split = (part.sum(0).double() - want).abs().max().item()
         e_fp32 = ((z.view(64, -1) @ mix.out_proj.weight.t()).double() - want).abs().max().item()
@@ -219,8 +219,8 @@ def test_split_precision_operands_and_gemms():
     assert mix.split_packs(act_bound=1e5) == {}     # operands outside the f16 range: the caller keeps the fp32 GEMMs
 
 
-@pytest.mark.parametrize("M,N,K,S", [(900, 256, 32768, 16), (131, 256, 4096, 2), (7, 100, 1024, 4), (128, 128, 64, 1), (128, 128, 32, 1),
-                                     (200, 130, 96, 1)])
+@pytest.mark.parametrize("M,N,K,S", [(900, 256, 32768, 32), (900, 256, 32768, 16), (131, 256, 4096, 2), (7, 100, 1024, 4),
+                                     (128, 128, 64, 1), (128, 128, 32, 1), (200, 130, 96, 1), (300, 700, 64, 2)])
 def test_outproj_kernel_vs_float64(M, N, K, S):
     """rac_outproj_fwd (hand-written split-K GEMM, LDS-DMA staging, source-side swizzle) against a float64 GEMM of the values
     its operand images hold: asymmetric integer-free random operands, ragged M / N (tile edges), every slice checked."""
@@ -245,6 +245,38 @@ def test_outproj_kernel_vs_float64(M, N, K, S):
         err = (part[s_].double() - want).abs().max().item()
         # dropped lo*lo term (2^-22 relative to the hi*hi terms) + fp32 accumulation of ks products
         assert err <= 3e-6 * float(want.abs().max()) + 1e-6 * float((zv.abs().max() * wv.abs().max())) * ks ** 0.5, (s_, err)
+
+
+@pytest.mark.parametrize("M,N,K", [(900, 4096, 256), (900, 65536, 256), (37, 520, 64), (129, 256, 32), (1, 4, 96)])
+def test_generator_kernel_vs_float64(M, N, K):
+    """rac_generator_fwd (the same kernel, persistent over the row tiles of a feature tile, affine epilogue) against float64:
+    ragged rows (tiles of unequal height, skipped MFMA tiles), ragged features (N % 256 != 0), bias, alpha; and the X line
+    image written by rac_rowgemm_fwd's prologue for K = 256."""
+    from racformer_amd.fused import SPLIT_ACT_SCALE, generator_fused, pack_gemm_split_weight, row_gemm, row_seg, rowgemm_launch
+    g = torch.Generator().manual_seed(M + N)
+    lin = torch.nn.Linear(K, N)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(N, K, generator=g) * 0.05)
+        lin.bias.copy_(torch.randn(N, generator=g))
+    lin = lin.to(DEV)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w_img, alpha = pack_gemm_split_weight(lin.weight)
+    if K == 256:
+        # the image as the decoder produces it: finished rows of a rowgemm prologue (here: plain copy of x), written beside a
+        # throw-away 16-column GEMM
+        img = torch.empty(M, 512, device=DEV, dtype=torch.float16)
+        dummy_w, dummy_out = torch.zeros(16, 256, device=DEV), torch.empty(M, 16, device=DEV)
+        rowgemm_launch([row_gemm([row_seg(x, split_out=img, split_lines=True)], dummy_w, None, dummy_out)], M)
+    else:
+        xs = x * SPLIT_ACT_SCALE
+        hi = xs.to(torch.float16)
+        lo = (xs - hi.float()).to(torch.float16)
+        img = torch.stack([hi.view(M, K // 32, 32), lo.view(M, K // 32, 32)], dim=2).reshape(M, K // 32 * 64).contiguous()
+    got = generator_fused(img, w_img, lin.bias, alpha)
+    want = x.double() @ lin.weight.double().t() + lin.bias.double()
+    e_split = (got.double() - want).abs().max().item()
+    e_fp32 = (lin(x).double() - want).abs().max().item()
+    assert tuple(got.shape) == (M, N) and e_split < 4 * e_fp32 + 1e-6, (e_split, e_fp32)
 
 
 @pytest.mark.parametrize("shape", [(8, 128, 128, 256, 64), (3, 16, 16, 256, 64), (2, 32, 64, 32, 32)])

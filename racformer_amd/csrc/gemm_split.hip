@@ -228,6 +228,145 @@ __global__ __launch_bounds__(768, 1) void gemm_split_kernel(const GemmSplitArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ W-stationary kernel
+// parameter_generator: out[m][n] = alpha * sum_k X[m][k] W[n][k] + bias[n] with K = 256 only -- per flop the tiled kernel
+// above has to take in as many operand bytes as a 32-times-longer K loop would, and the LDS-DMA intake of a CU (~32 GB/s
+// with the matrix pipe busy) makes it slower than a library GEMM (151 us against 127 us).  Here the WEIGHTS never pass
+// through LDS: a workgroup owns 256 features, each of its 8 waves keeps the hi and lo fragments of its 32 features for
+// the whole K in registers (2 tiles x 8 K steps x 2 x 4 = 128 VGPRs, loaded once, straight from the image), and only
+// the 0.9 MB X image streams through a ring of four 32-row stages (32 KB each, whole K per row, LDS-DMA, one 1 KB piece
+// = one row).  Per stage and SIMD 192 MFMAs (1.5 us) stand against 32 KB of intake (22 GB/s): matrix-pipe-bound.
+// All eight waves multiply AND load (four pieces each per stage; the two waves of a SIMD alternate between the LDS-DMA
+// issue and their MFMA block); stores, LDS-DMA and loads share vmcnt, so the counted wait covers the stores in between.
+#define GW_ROWS 32                          /* X rows per stage */
+#define GW_STAGE (GW_ROWS * 1024)           /* bytes: K = 256 -> 8 lines = 1 KB per row */
+#define GW_STAGES 4
+
+struct GenArgs {
+    const char *x;      // X image [M][8 lines]
+    const char *w;      // W image [N][8 lines]
+    const float *bias;  // [N] or null
+    float *out;         // [M][ld_out]
+    float alpha;
+    int M, N;
+    long ld_out;
+};
+
+__global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
+{
+    extern __shared__ char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int n0 = blockIdx.x * 256 + 32 * wave;          // this wave's 32 features
+    const int nstages = (g.M + GW_ROWS - 1) / GW_ROWS;
+
+    // ---- X loader role: piece = one row (1 KB); wave w moves rows w, w+8, w+16, w+24 of every stage.  LDS slot `lane` of
+    // the row receives the row's 16-byte chunk lane ^ (row & 15) (source-side swizzle, see the fragment reads)
+    // (ring slots are compile-time constants everywhere: with a run-time slot index hipcc cannot tell an LDS-DMA into one
+    //  slot from the fragment reads of another and waits vmcnt(0) before every first read -- the pipeline collapses)
+    auto issue = [&](int st, int slot) {
+        char *stage = lds + slot * GW_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave + 8 * j;
+            int row = st * GW_ROWS + r;
+            row = row < g.M ? row : g.M - 1;           // rows past the end re-read the last row; never stored
+            const char *src = g.x + (size_t)row * 1024 + (size_t)((lane ^ (r & 15)) * 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(stage + r * 1024), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
+    if (nstages > 2) issue(2, 2);
+
+    // ---- this wave's weights: fragment (tile t, K step ks) = W rows n0 + 16t + li, 16-byte chunk lk of the hi / lo half
+    gs_h8 wh[2][8], wl[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int n = n0 + 16 * t + li;
+        n = n < g.N ? n : g.N - 1;
+        const char *wp = g.w + (size_t)n * 1024 + lk * 16;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            wh[t][ks] = *reinterpret_cast<const gs_h8 *>(wp + ks * 128);
+            wl[t][ks] = *reinterpret_cast<const gs_h8 *>(wp + ks * 128 + 64);
+        }
+    }
+    gs_f4 bias4[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + 16 * t + 4 * lk;
+        bias4[t] = (g.bias && n + 3 < g.N) ? *reinterpret_cast<const gs_f4 *>(g.bias + n) : (gs_f4){0.f, 0.f, 0.f, 0.f};
+    }
+    // (the waits below are spelled out: everything issued so far -- 12 pieces and 32 weight loads -- has to be complete)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment read: row r = 16j + li of the stage, chunk c = 8 ks + (hi: lk, lo: 4 + lk), LDS slot c ^ (r & 15) = c ^ li
+    for (int st0 = 0; st0 < nstages; st0 += GW_STAGES) {
+#pragma unroll
+    for (int u = 0; u < GW_STAGES; ++u) {
+        const int st = st0 + u;
+        if (st >= nstages)
+            break;
+        if (st + 3 < nstages)
+            issue(st + 3, (u + 3) & (GW_STAGES - 1));    // its ring slot was read in stage st-1 (barrier below)
+        const char *S = lds + u * GW_STAGE;
+        gs_f4 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[t][j] = (gs_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char *rowp = S + (16 * j + li) * 1024;
+                const gs_h8 xh = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + lk) ^ li) * 16));
+                const gs_h8 xl = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + 4 + lk) ^ li) * 16));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t][ks], xh, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][ks], xl, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][ks], xh, acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+        // C/D layout: col = li (X row), rows 4 lk + r = four consecutive features: one 16-byte store each
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = st * GW_ROWS + 16 * j + li;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int n = n0 + 16 * t + 4 * lk;
+                const gs_f4 v = acc[t][j] * g.alpha + bias4[t];
+                if (row < g.M) {
+                    if (n + 3 < g.N) {
+                        *reinterpret_cast<gs_f4 *>(g.out + (size_t)row * g.ld_out + n) = v;
+                    } else {
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N)
+                                g.out[(size_t)row * g.ld_out + n + r] = acc[t][j][r] * g.alpha + (g.bias ? g.bias[n + r] : 0.f);
+                    }
+                }
+            }
+        }
+        // stage st+1 must have landed before anyone reads it.  Issue order of this wave's vector-memory operations:
+        //   ... P(st+1) S(st-2) | P(st+2) S(st-1) | P(st+3) S(st)      (P: 4 pieces, S: up to 4 stores)
+        // so at most 20 younger operations may remain outstanding behind P(st+1); towards the end fewer pieces follow.
+        if (st + 3 < nstages)
+            asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+        else if (st + 2 < nstages)
+            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    }
+}
+
 // ---- weight packer: nn.Linear weight [N][K] f32 -> image [N][K/32][hi 32 | lo 32] f16 of weight * scale -------------------
 __global__ __launch_bounds__(256) void gemm_split_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ img, long n4,
                                                               float scale)
@@ -294,11 +433,25 @@ extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const
     RAC_CHECK_ARG(x_image && w_image && out, "rac_generator_fwd: null pointer");
     RAC_CHECK_ARG(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && ld_out >= N && ld_out % 4 == 0 && N % 4 == 0,
                   "rac_generator_fwd: M=%d N=%d K=%d ld_out=%ld (K %% 32, N %% 4, ld_out %% 4 must be 0)", M, N, K, ld_out);
+    if (K == 256) {
+        GenArgs a;
+        a.x = reinterpret_cast<const char *>(x_image);
+        a.w = reinterpret_cast<const char *>(w_image);
+        a.bias = bias; a.out = out; a.alpha = alpha; a.M = M; a.N = N; a.ld_out = ld_out;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(generator_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      GW_STAGES * GW_STAGE);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(generator_ws_kernel, dim3((N + 255) / 256), dim3(512), GW_STAGES * GW_STAGE, (hipStream_t)stream, a);
+        return rac_launch_status("rac_generator_fwd");
+    }
     GemmSplitArgs g;
     g.x = reinterpret_cast<const char *>(x_image);
     g.w = reinterpret_cast<const char *>(w_image);
     g.out = out; g.bias = bias; g.alpha = alpha; g.affine = 1; g.ld_out = ld_out;
     g.M = M; g.N = N; g.K = K; g.slices = 1;
-    // one workgroup per W tile walks all row tiles: its 256 W rows are fetched once and stay in its XCD's L2
+    // other K: the tiled kernel; one workgroup per W tile walks all row tiles (its W rows stay in its XCD's L2)
     return gs_launch(g, (M + GS_TX - 1) / GS_TX, (hipStream_t)stream, "rac_generator_fwd");
 }

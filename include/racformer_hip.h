@@ -144,6 +144,17 @@ int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float
                          int dim, const float *pc_range, const float *depth_base, float d_region, int dtype,
                          void *stream);
 
+/* The same kernel for the BEV streams of one decoder layer (radar, LSS) in ONE launch: same queries, boxes and time_diff,
+ * per stream its own value maps, Linear outputs (same row strides) and output.  HOST arrays of nstreams (1..2) device
+ * pointers.  The second stream's workgroups start as the first one's drain and its keypoint prologue runs under the first
+ * stream's gathers (models/racformer_transformer.py:246-249 runs the two modules back to back). */
+int rac_bev_sampling_multi_fwd(int nstreams, const void *const *values, const float *const *offsets,
+                               const float *const *ray_logits, const float *const *scale_logits,
+                               const float *const *queue_logits, float *const *outs, const float *query_bbox,
+                               const float *box_table, const float *time_diff, int ld_off, int ld_ray, int ld_scale,
+                               int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W, int dim,
+                               const float *pc_range, const float *depth_base, float d_region, int dtype, void *stream);
+
 /* Scale-adaptive self-attention core (QK^T + distance mask + softmax + AV), one kernel.
  * Replaces calc_bbox_dists, the [B*heads,Q,Q] mask and nn.MultiheadAttention's attention product
  * (models/racformer_transformer.py:296-335); in_proj / out_proj remain library GEMMs.
@@ -232,7 +243,7 @@ int rac_outproj_fwd(const void *z_image, const void *w_image, float *partials, i
  *   x_image : device f16 line image [M][K/32][hi 32 | lo 32]   (rac_rowgemm_fwd's split_out, split_layout = RAC_SPLIT_LINES)
  *   w_image : device f16 line image [N][K/32][hi 32 | lo 32]   (rac_gemm_split_pack_fwd);  bias device f32 [N] or NULL
  *   out     : device f32, row m at out + m*ld_out;  K % 32 == 0, N % 4 == 0, ld_out % 4 == 0 */
-int rac_generator_fwd(const void *x_image, const void *w_image, const float *bias, float alpha, float *out, long ld_out, int M,
+int rac_generator_fwd(const void *x_image, const void *w_image, const float *bias, float alpha, float *out, int64_t ld_out, int M,
                       int N, int K, void *stream);
 
 /* The temporal-fusion convolution of RadarBEVTemporalEncoder (3x3, stride 1, pad 1, Cin -> 256; the 193-GFLOP

@@ -39,7 +39,7 @@ SIGNATURES = {
     "rac_rowgemm_fwd": (_i, [_vp, _i, _i, _vp]),
     "rac_gemm_split_pack_fwd": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "rac_outproj_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "rac_generator_fwd": (_i, [_vp, _vp, _vp, _f, _vp, ctypes.c_long, _i, _i, _i, _vp]),
+    "rac_generator_fwd": (_i, [_vp, _vp, _vp, _f, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
     "rac_gru_gate_fwd": (_i, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
     "rac_upsample2x_fwd": (_i, [_vp, _vp, ctypes.c_int64, _i, _i, _vp]),
     "rac_absmax_fwd": (_i, [_vp, _vp, _i, _f, _vp, _vp]),
@@ -47,6 +47,7 @@ SIGNATURES = {
     "rac_conv3x3_fwd": (_i, [_vp] * 5 + [_f, _vp] + [_i] * 5 + [_vp]),
     "rac_conv3x3s2_fwd": (_i, [_vp] * 4 + [_f, _vp] + [_i] * 7 + [_vp]),
     "rac_bev_sampling_fwd": (_i, [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
+    "rac_bev_sampling_multi_fwd": (_i, [_i] + [_vp] * 9 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
 }
 
 

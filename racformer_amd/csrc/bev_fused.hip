@@ -22,17 +22,24 @@
 #define BEV_MAX_DEPTH 16
 #define BEV_TWO_PI 6.283185307179586f
 
-struct BevArgs {
+#define BEV_MAX_STREAMS 2
+// one BEV stream (radar / LSS): its value maps and the Linear outputs of its sampling module; blockIdx.y selects it, so
+// the streams of a decoder layer -- same queries, same boxes -- share ONE launch: the second stream's workgroups start
+// as the first one's drain, its keypoint prologue runs under the first stream's gathers.
+struct BevStream {
     const void *value;
-    const float *qbox;       // [B,Q,10]
-    const float *box;        // [B,Q,8] from rac_box_prep_fwd
     const float *off;        // [B,Q,heads*P*2]
     const float *ray;        // [B,Q,D]
     const float *scale;      // [B,Q,heads*P] logits
     const float *queue;      // [B,Q,T] logits
-    const float *time_diff;  // [B,T]
     float *out;              // [B,Q,heads*64]
     float *loc_out;          // optional [B,Q,heads,T,P,2]
+};
+struct BevArgs {
+    BevStream s[BEV_MAX_STREAMS];
+    const float *qbox;       // [B,Q,10]
+    const float *box;        // [B,Q,8] from rac_box_prep_fwd
+    const float *time_diff;  // [B,T]
     float depth_base[BEV_MAX_DEPTH];
     float pc[6];
     float d_region;
@@ -42,7 +49,7 @@ struct BevArgs {
     int xcd_remap;           // 1: blocks that share an XCD (blockIdx & 7) take a contiguous range of items (speed only)
 };
 
-__device__ __forceinline__ void bev_keypoint(const BevArgs &a, int bq, int tq, int q, int h, int p, float *loc2)
+__device__ __forceinline__ void bev_keypoint(const BevArgs &a, const BevStream &s, int bq, int tq, int q, int h, int p, float *loc2)
 {
     const float *qb = a.qbox + ((size_t)bq * a.Q + q) * 10;
     const float sx = a.pc[3] - a.pc[0], sy = a.pc[4] - a.pc[1];
@@ -52,7 +59,7 @@ __device__ __forceinline__ void bev_keypoint(const BevArgs &a, int bq, int tq, i
     const float cx = xn0 * sx + a.pc[0], cy = yn0 * sy + a.pc[1];
     const float yaw = atan2f(qb[6], qb[7]);
     const float cs = cosf(yaw), sn = sinf(yaw);
-    const float *o = a.off + ((size_t)bq * a.Q + q) * a.ld_off + ((size_t)h * a.P + p) * 2;
+    const float *o = s.off + ((size_t)bq * a.Q + q) * a.ld_off + ((size_t)h * a.P + p) * 2;
     const float dx = expf(qb[3]) * o[0], dy = expf(qb[4]) * o[1];
     float px = cx + (dx * cs - dy * sn);
     float py = cy + (dx * sn + dy * cs);
@@ -64,7 +71,7 @@ __device__ __forceinline__ void bev_keypoint(const BevArgs &a, int bq, int tq, i
     float dist = sqrtf(ex * ex + ey * ey) / 65.0f;
     const float th = fmodf(atan2f(ey, ex) + BEV_TWO_PI, BEV_TWO_PI) / BEV_TWO_PI;
     const int dd = p % a.D;
-    const float sg = 1.f / (1.f + expf(-a.ray[((size_t)bq * a.Q + q) * a.ld_ray + dd]));
+    const float sg = 1.f / (1.f + expf(-s.ray[((size_t)bq * a.Q + q) * a.ld_ray + dd]));
     dist += a.depth_base[dd] + (sg * 2.f - 1.f) * a.d_region / (float)a.D / 2.f;
     const float ang = th * BEV_TWO_PI, rad = dist * 65.0f;
     loc2[0] = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f);
@@ -103,6 +110,7 @@ template <typename FT>
 __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs a)
 {
     extern __shared__ float smem[];
+    const BevStream &s = a.s[blockIdx.y];
     const int tid = threadIdx.x;
     const int c4 = tid & 15, grp = tid >> 4;
     const int k = grp >> 2, ts = grp & 3;       // item within the workgroup, frame subset
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
         const int kk = tid / P, p = tid - kk * P;
         const int it = i0 + kk, q = it / a.heads, h = it % a.heads;
         const float *bt = a.box + ((size_t)b * a.Q + q) * 8;
-        const float *o = a.off + ((size_t)b * a.Q + q) * a.ld_off + ((size_t)h * P + p) * 2;
+        const float *o = s.off + ((size_t)b * a.Q + q) * a.ld_off + ((size_t)h * P + p) * 2;
         const float dx = bt[3] * o[0], dy = bt[4] * o[1];
         sbase[tid * 2] = bt[0] + (dx * bt[6] - dy * bt[7]);
         sbase[tid * 2 + 1] = bt[1] + (dx * bt[7] + dy * bt[6]);
@@ -143,13 +151,13 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
     if (tid >= 128 && tid < 128 + nitems * D && a.B == 1) {
         const int kk = (tid - 128) / D, dd = (tid - 128) - kk * D;
         const int q = (i0 + kk) / a.heads;
-        const float sg = 1.f / (1.f + expf(-a.ray[((size_t)b * a.Q + q) * a.ld_ray + dd]));
+        const float sg = 1.f / (1.f + expf(-s.ray[((size_t)b * a.Q + q) * a.ld_ray + dd]));
         sdoff[kk * BEV_MAX_DEPTH + dd] = a.depth_base[dd] + (sg * 2.f - 1.f) * a.d_region / (float)D / 2.f;
     }
     if (tid >= 192 && tid < 192 + nitems) {
         const int kk = tid - 192;
         const int it = i0 + kk, q = it / a.heads, h = it % a.heads;
-        const float *qg = a.queue + ((size_t)b * a.Q + q) * a.ld_queue;
+        const float *qg = s.queue + ((size_t)b * a.Q + q) * a.ld_queue;
         float mx = qg[0];
         for (int t = 1; t < T; ++t)
             mx = fmaxf(mx, qg[t]);
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
         for (int t = 0; t < T; ++t)
             sq[kk * T + t] /= sum;
         if (a.B == 1) {
-            const float *lg = a.scale + ((size_t)b * a.Q + q) * a.ld_scale + (size_t)h * P;
+            const float *lg = s.scale + ((size_t)b * a.Q + q) * a.ld_scale + (size_t)h * P;
             float m2 = lg[0];
             for (int p = 1; p < P; ++p)
                 m2 = fmaxf(m2, lg[p]);
@@ -188,9 +196,9 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
         } else {
             const int fi = b * T + t;                // value frame index
             const int bq = fi % a.B, tq = fi / a.B;  // whose locations it is paired with (quirk Q2)
-            bev_keypoint(a, bq, tq, q, h, p, sloc + i * 2);
+            bev_keypoint(a, s, bq, tq, q, h, p, sloc + i * 2);
             // point softmax of the paired batch b' (rare path: every thread redoes the P-term reduction)
-            const float *lg = a.scale + ((size_t)bq * a.Q + q) * a.ld_scale + (size_t)h * P;
+            const float *lg = s.scale + ((size_t)bq * a.Q + q) * a.ld_scale + (size_t)h * P;
             float wmax = lg[0];
             for (int pj = 1; pj < P; ++pj)
                 wmax = fmaxf(wmax, lg[pj]);
@@ -222,8 +230,8 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
             stab[i * 8 + 6] = lh * hw * wgt;
             stab[i * 8 + 7] = lh * lw * wgt;
         }
-        if (a.loc_out) {
-            float *lo = a.loc_out + (((((size_t)b * a.Q + q) * a.heads + h) * T + t) * P + p) * 2;
+        if (s.loc_out) {
+            float *lo = s.loc_out + (((((size_t)b * a.Q + q) * a.heads + h) * T + t) * P + p) * 2;
             lo[0] = sloc[i * 2];
             lo[1] = sloc[i * 2 + 1];
         }
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
                 const bool act = j < total;
                 const int jj = act ? j : total - 1;
                 const int t = jj / npp, p = ts + BEV_TS * (jj - t * npp);
-                const FT *base = (const FT *)a.value + ((size_t)(b * T + t) * keys * a.heads + h) * 64 + c4 * 4;
+                const FT *base = (const FT *)s.value + ((size_t)(b * T + t) * keys * a.heads + h) * 64 + c4 * 4;
                 const float *e = stab + (k * TP + t * P + p) * 8;          // same address for the 16 lanes of the group
                 const rac_f4 ei = *reinterpret_cast<const rac_f4 *>(e), ew = *reinterpret_cast<const rac_f4 *>(e + 4);
                 const int o0 = __float_as_int(ei.x), o1 = __float_as_int(ei.y), o2 = __float_as_int(ei.z), o3 = __float_as_int(ei.w);
@@ -282,18 +290,17 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
             const rac_f4 pz = *reinterpret_cast<const rac_f4 *>(spart + (k * BEV_TS + u) * 64 + c4 * 4);
             o.x += pz.x; o.y += pz.y; o.z += pz.z; o.w += pz.w;
         }
-        *reinterpret_cast<rac_f4 *>(a.out + ((size_t)b * per_b + it) * 64 + c4 * 4) = o;
+        *reinterpret_cast<rac_f4 *>(s.out + ((size_t)b * per_b + it) * 64 + c4 * 4) = o;
     }
 }
 
-extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float *box_table,
-                                    const float *offsets,
-                                    const float *ray_logits, const float *scale_logits, const float *queue_logits,
-                                    const float *time_diff, float *out, float *loc_out, int ld_off, int ld_ray,
-                                    int ld_scale, int ld_queue, int B, int T, int Q, int heads,
-                                    int NP, int D, int H, int W, int dim, const float *pc_range,
-                                    const float *depth_base, float d_region, int dtype, void *stream)
+static int bev_launch(int nstreams, const void *const *values, const float *const *offsets, const float *const *ray_logits,
+                      const float *const *scale_logits, const float *const *queue_logits, float *const *outs, float *const *loc_outs,
+                      const float *query_bbox, const float *box_table, const float *time_diff, int ld_off, int ld_ray,
+                      int ld_scale, int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W, int dim,
+                      const float *pc_range, const float *depth_base, float d_region, int dtype, void *stream)
 {
+    RAC_CHECK_ARG(nstreams >= 1 && nstreams <= BEV_MAX_STREAMS, "rac_bev_sampling_fwd: %d streams (1..%d)", nstreams, BEV_MAX_STREAMS);
     RAC_CHECK_ARG(dim == 64, "rac_bev_sampling_fwd: dim=%d (the fused kernel is built for 64 channels per head)", dim);
     RAC_CHECK_ARG(B >= 0 && Q >= 0 && T >= 1 && heads >= 1 && NP >= 1 && D >= 1 && D <= BEV_MAX_DEPTH && H >= 1 && W >= 1,
                   "rac_bev_sampling_fwd: bad sizes B=%d T=%d Q=%d heads=%d NP=%d D=%d H=%d W=%d", B, T, Q, heads, NP, D, H, W);
@@ -306,12 +313,17 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
         return 0;
     RAC_CHECK_ARG(box_table != nullptr, "rac_bev_sampling_fwd: box_table is null (run rac_box_prep_fwd first)");
     RAC_CHECK_ARG(BEV_GI * P <= 128 && BEV_GI * D <= 64, "rac_bev_sampling_fwd: NP*D=%d (max %d) or D=%d (max %d) exceed the workgroup's staging roles", P, 128 / BEV_GI, D, 64 / BEV_GI);
-    RAC_CHECK_ARG(value && query_bbox && offsets && ray_logits && scale_logits && queue_logits && time_diff && out &&
-                      pc_range && depth_base,
+    RAC_CHECK_ARG(values && offsets && ray_logits && scale_logits && queue_logits && outs && query_bbox && time_diff && pc_range && depth_base,
                   "rac_bev_sampling_fwd: null pointer");
     BevArgs a;
-    a.value = value; a.qbox = query_bbox; a.box = box_table; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
-    a.queue = queue_logits; a.time_diff = time_diff; a.out = out; a.loc_out = loc_out;
+    for (int i = 0; i < BEV_MAX_STREAMS; ++i) {
+        const int j = i < nstreams ? i : 0;
+        RAC_CHECK_ARG(values[j] && offsets[j] && ray_logits[j] && scale_logits[j] && queue_logits[j] && outs[j],
+                      "rac_bev_sampling_fwd: null pointer in stream %d", j);
+        a.s[i].value = values[j]; a.s[i].off = offsets[j]; a.s[i].ray = ray_logits[j]; a.s[i].scale = scale_logits[j];
+        a.s[i].queue = queue_logits[j]; a.s[i].out = outs[j]; a.s[i].loc_out = loc_outs ? loc_outs[j] : nullptr;
+    }
+    a.qbox = query_bbox; a.box = box_table; a.time_diff = time_diff;
     for (int i = 0; i < BEV_MAX_DEPTH; ++i)
         a.depth_base[i] = i < D ? depth_base[i] : 0.f;
     for (int i = 0; i < 6; ++i)
@@ -321,11 +333,34 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
     a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale; a.ld_queue = ld_queue;
     a.blocks_per_b = (Q * heads + BEV_GI - 1) / BEV_GI;
     a.xcd_remap = 1;
-    const int nb = B * a.blocks_per_b;
+    const dim3 grid(B * a.blocks_per_b, nstreams);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RAC_F32)
-        hipLaunchKernelGGL(bev_sampling_d64_kernel<float>, dim3(nb), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(bev_sampling_d64_kernel<float>, grid, dim3(256), lds, st, a);
     else
-        hipLaunchKernelGGL(bev_sampling_d64_kernel<unsigned short>, dim3(nb), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(bev_sampling_d64_kernel<unsigned short>, grid, dim3(256), lds, st, a);
     return rac_launch_status("rac_bev_sampling_fwd");
+}
+
+extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, const float *box_table,
+                                    const float *offsets,
+                                    const float *ray_logits, const float *scale_logits, const float *queue_logits,
+                                    const float *time_diff, float *out, float *loc_out, int ld_off, int ld_ray,
+                                    int ld_scale, int ld_queue, int B, int T, int Q, int heads,
+                                    int NP, int D, int H, int W, int dim, const float *pc_range,
+                                    const float *depth_base, float d_region, int dtype, void *stream)
+{
+    return bev_launch(1, &value, &offsets, &ray_logits, &scale_logits, &queue_logits, &out, &loc_out, query_bbox, box_table, time_diff,
+                      ld_off, ld_ray, ld_scale, ld_queue, B, T, Q, heads, NP, D, H, W, dim, pc_range, depth_base, d_region, dtype, stream);
+}
+
+extern "C" int rac_bev_sampling_multi_fwd(int nstreams, const void *const *values, const float *const *offsets,
+                                          const float *const *ray_logits, const float *const *scale_logits,
+                                          const float *const *queue_logits, float *const *outs, const float *query_bbox,
+                                          const float *box_table, const float *time_diff, int ld_off, int ld_ray, int ld_scale,
+                                          int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W, int dim,
+                                          const float *pc_range, const float *depth_base, float d_region, int dtype, void *stream)
+{
+    return bev_launch(nstreams, values, offsets, ray_logits, scale_logits, queue_logits, outs, nullptr, query_bbox, box_table, time_diff,
+                      ld_off, ld_ray, ld_scale, ld_queue, B, T, Q, heads, NP, D, H, W, dim, pc_range, depth_base, d_region, dtype, stream);
 }

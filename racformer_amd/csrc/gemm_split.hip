@@ -427,12 +427,12 @@ extern "C" int rac_outproj_fwd(const void *z_image, const void *w_image, float *
     return gs_launch(g, 1, (hipStream_t)stream, "rac_outproj_fwd");
 }
 
-extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const float *bias, float alpha, float *out, long ld_out,
+extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const float *bias, float alpha, float *out, int64_t ld_out,
                                  int M, int N, int K, void *stream)
 {
     RAC_CHECK_ARG(x_image && w_image && out, "rac_generator_fwd: null pointer");
     RAC_CHECK_ARG(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && ld_out >= N && ld_out % 4 == 0 && N % 4 == 0,
-                  "rac_generator_fwd: M=%d N=%d K=%d ld_out=%ld (K %% 32, N %% 4, ld_out %% 4 must be 0)", M, N, K, ld_out);
+                  "rac_generator_fwd: M=%d N=%d K=%d ld_out=%lld (K %% 32, N %% 4, ld_out %% 4 must be 0)", M, N, K, (long long)ld_out);
     if (K == 256) {
         GenArgs a;
         a.x = reinterpret_cast<const char *>(x_image);

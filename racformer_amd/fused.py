@@ -124,6 +124,49 @@ def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits,
     return (out, loc_out) if debug else out
 
 
+def bev_sampling_multi_fused(streams, hw, query_bbox, time_diff, num_frames, num_heads, num_points, depth_num, pc_range,
+                             d_region, box_table, out):
+    """The BEV streams of one decoder layer in one launch (rac_bev_sampling_multi_fwd).  ``streams``: list of
+    (value [B*T,H*W,heads,64], offsets, ray_logits, scale_logits, queue_logits) with equal row strides; ``out`` [n,B,Q,heads*64]."""
+    B, Q, _ = query_bbox.shape
+    T, Hn, NP, D = num_frames, num_heads, num_points, depth_num
+    P = NP * D
+    H, W = hw
+    n = len(streams)
+    if tuple(out.shape) != (n, B, Q, Hn * 64) or not out.is_contiguous():
+        raise RuntimeError("bev_sampling_multi_fused: out must be a contiguous [streams,B,Q,heads*64] tensor")
+    lds = None
+    cols = [[], [], [], [], []]
+    for value, off, ray, sc, qu in streams:
+        _lib.require_gpu(value, what="bev_sampling_multi_fused")
+        if tuple(value.shape) != (B * T, H * W, Hn, 64):
+            raise RuntimeError(f"bev_sampling_multi_fused: value must be [{B * T},{H * W},{Hn},64], got {tuple(value.shape)}")
+        p_off, ld_off = _rows(off, Hn * P * 2, "bev_sampling_multi_fused(offsets)")
+        p_ray, ld_ray = _rows(ray, D, "bev_sampling_multi_fused(ray_logits)")
+        p_sc, ld_sc = _rows(sc, Hn * P, "bev_sampling_multi_fused(scale_logits)")
+        p_qu, ld_qu = _rows(qu, T, "bev_sampling_multi_fused(queue_logits)")
+        if lds is None:
+            lds = (ld_off, ld_ray, ld_sc, ld_qu)
+        elif lds != (ld_off, ld_ray, ld_sc, ld_qu) or value.dtype != streams[0][0].dtype:
+            raise RuntimeError("bev_sampling_multi_fused: the streams must share row strides and dtype")
+        for c, v in zip(cols, (value.data_ptr(), p_off.value, p_ray.value, p_sc.value, p_qu.value)):
+            c.append(v)
+    arr = [(ctypes.c_void_p * n)(*c) for c in cols]
+    outs = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
+    pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    ev = _lib.timer.record("bev_sampling_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_bev_sampling_multi_fwd(
+        n, arr[0], arr[1], arr[2], arr[3], arr[4], outs, _lib.ptr(query_bbox), _lib.ptr(box_table), _lib.ptr(time_diff),
+        lds[0], lds[1], lds[2], lds[3], B, T, Q, Hn, NP, D, H, W, 64, pc, _depth_base(float(d_region), D), float(d_region),
+        _lib.dtype_code(streams[0][0]), _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_bev_sampling_multi_fwd")
+    return out
+
+
 def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range, box_table=None):
     """qkv [B,Q,3*E] (q|k|v, each [heads, E/heads]; may be a column slice), tau [B,Q,heads] ->
     attention output [B,Q,E] before out_proj."""

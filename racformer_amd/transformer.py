@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add_ln, bev_sampling_fused, box_prep,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add_ln, bev_sampling_fused, bev_sampling_multi_fused, box_prep,
                     generator_fused, gru_gate_fused, layer_boundary_fused, mixing_fused, outproj_fused, pack_conv3x3_weight,
                     pack_gemm_split_weight,
                     pe_head, refine_fused, row_gemm,
@@ -1014,12 +1014,21 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         r_off, r_ray, r_sc, r_qu = lin[3:7]
         l_off, l_ray, l_sc, l_qu = lin[7:11]
         bev = new(2, B, Q, E)
-        bev_sampling_fused(prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff,
-                           rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region,
-                           box_table=table, out=bev[0])
-        bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
-                           lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
-                           box_table=table, out=bev[1])
+        same = prepared["radar_hw"] == prepared["lss_hw"] and prepared["radar_value"].dtype == prepared["lss_value"].dtype and \
+            (rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num) == (lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num)
+        if same:
+            # radar and LSS stream in one launch (same queries, same boxes): the second stream's workgroups fill the CUs as
+            # the first one's drain
+            bev_sampling_multi_fused([(prepared["radar_value"], r_off, r_ray, r_sc, r_qu), (prepared["lss_value"], l_off, l_ray, l_sc, l_qu)],
+                                     prepared["radar_hw"], qb, time_diff, rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num,
+                                     rb.pc_range, d_region, table, bev)
+        else:
+            bev_sampling_fused(prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff,
+                               rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region,
+                               box_table=table, out=bev[0])
+            bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
+                               lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
+                               box_table=table, out=bev[1])
         sampled_feat = self._sample(qb, x1, mlvl_feats, img_metas, d_region, lin[0:3], table)
         partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)
         p_scale = packs["out_alpha"] if packs else 1.0

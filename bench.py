@@ -301,7 +301,8 @@ def main():
         merged = dp.merge_interleaved(out, world)           # one sample per rank per step, dataset order
         assert tuple(merged.shape) == (world, 300, 11)
     msmv_ms = timer.mean_ms("sampling4d_fwd") or timer.mean_ms("msmv_fwd")
-    msda_ms = aux.mean_ms("bev_sampling_fwd") or aux.mean_ms("msda_fwd")
+    bev_streams = 2 if aux.mean_ms("bev_sampling_x2_fwd") else 1        # radar + LSS in one launch
+    msda_ms = aux.mean_ms("bev_sampling_x2_fwd") or aux.mean_ms("bev_sampling_fwd") or aux.mean_ms("msda_fwd")
 
     # algorithmic bytes of the msmv launches of one forward (untimed, instrumented pass)
     cap = _lib.KernelTimer()
@@ -327,8 +328,8 @@ def main():
     # MSDA algorithmic bytes of SURVEY 8(d) for one BEV launch (value stream read once + loc + weights + output)
     bev_h, bev_w = cfg.bev_hw
     bev_pts = cfg.batch * cfg.num_frames * cfg.num_query * 4 * cfg.num_points_bev * cfg.bev_depth_num
-    bev_alg = min(bev_pts * 4 * 64 * elt, cfg.batch * cfg.num_frames * bev_h * bev_w * 256 * elt) + bev_pts * 2 * 4 + bev_pts * 4 \
-        + cfg.batch * cfg.num_frames * cfg.num_query * 256 * 4
+    bev_alg = bev_streams * (min(bev_pts * 4 * 64 * elt, cfg.batch * cfg.num_frames * bev_h * bev_w * 256 * elt) + bev_pts * 2 * 4
+                             + bev_pts * 4 + cfg.batch * cfg.num_frames * cfg.num_query * 256 * 4)
 
     # Dense contractions of the path on the matrix cores.  The big ones run as split-precision products: operands
     # split into 16-bit terms (f16 hi/lo; bf16 x3 for the sampled features), 3 (6) cross products accumulated in
@@ -379,7 +380,7 @@ def main():
                      "avg_launch_ms": msmv_ms, "launches_per_step": len(cap.captured),
                      "algorithmic_bytes_per_launch": b_alg, "algorithmic_bytes_all_in_range": b_alg_closed,
                      "in_range_fraction_per_layer": in_frac,
-                     "bev_sampling": {"avg_launch_ms": msda_ms, "algorithmic_bytes_per_launch": bev_alg,
+                     "bev_sampling": {"avg_launch_ms": msda_ms, "streams_per_launch": bev_streams, "algorithmic_bytes_per_launch": bev_alg,
                                       "achieved": bev_alg / (msda_ms * 1e-3) / 1e9 if msda_ms else None,
                                       "frac": bev_alg / (msda_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if msda_ms else None,
                                       "traffic": bev_traffic},

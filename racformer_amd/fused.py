@@ -154,7 +154,7 @@ def bev_sampling_multi_fused(streams, hw, query_bbox, time_diff, num_frames, num
     arr = [(ctypes.c_void_p * n)(*c) for c in cols]
     outs = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i in range(n)])
     pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
-    ev = _lib.timer.record("bev_sampling_fwd") if _lib.timer is not None else None
+    ev = _lib.timer.record(f"bev_sampling_x{n}_fwd") if _lib.timer is not None else None
     if ev:
         ev[0].record()
     rc = _lib.lib().rac_bev_sampling_multi_fwd(

@@ -396,25 +396,6 @@ def test_rowgemm_kernel(rows):
     assert (o3.double() - w3).abs().max().item() < 1e-4 * w3.abs().max().item()
 
 
-@pytest.mark.parametrize("M", [900, 257, 16])
-def test_gemm_f16x3_kernel(M):
-    """rac_gemm_f16x3_fwd (hand-written split-precision GEMM) against float64, beside the fp32 rocBLAS GEMM; the A image
-    comes from rac_rowgemm_fwd's chunked split output."""
-    from racformer_amd.fused import gemm_f16x3, pack_gemm_weight_f16x3, row_gemm, row_seg, rowgemm_launch
-    torch.manual_seed(M)
-    lin = torch.nn.Linear(256, 1024).to(DEV)
-    x = torch.randn(M, 256, device=DEV) * 3.0
-    img = torch.empty(M, 512, device=DEV, dtype=torch.float16)
-    dummy_w, dummy_o = torch.zeros(16, 256, device=DEV), torch.empty(M, 16, device=DEV)
-    rowgemm_launch([row_gemm([row_seg(x, split_out=img, split_chunked=True)], dummy_w, None, dummy_o)], M)
-    w_img, alpha = pack_gemm_weight_f16x3(lin.weight)
-    got = gemm_f16x3(img, w_img, lin.bias, alpha)
-    want = x.double() @ lin.weight.double().t() + lin.bias.double()
-    e_own = (got.double() - want).abs().max().item()
-    e_fp32 = (lin(x).double() - want).abs().max().item()
-    assert e_own < 4 * e_fp32 + 1e-6, (e_own, e_fp32)
-
-
 def test_composed_radar_value_stream():
     """value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack, per-pixel bias in the
     convolution's epilogue) against the sequential evaluation temporal_encoder -> + pos -> value_proj."""

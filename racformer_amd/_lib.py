@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libracformer_hip.so")
+# (RACFORMER_HIP_LIB: another build of the same library, for A/B experiments of tools/exp_*.py; never set in tests or bench)
+LIB_PATH = os.environ.get("RACFORMER_HIP_LIB") or os.path.join(_HERE, "csrc", "libracformer_hip.so")
 RAC_F32, RAC_BF16 = 0, 1
 OUT_SQCP, OUT_BQGTPC = 0, 1
 MIX_F32, MIX_F16X3 = 0, 1

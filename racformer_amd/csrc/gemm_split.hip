@@ -238,9 +238,6 @@ __global__ __launch_bounds__(768, 1) void gemm_split_kernel(const GemmSplitArgs 
 // = one row).  Per stage and SIMD 192 MFMAs (1.5 us) stand against 32 KB of intake (22 GB/s): matrix-pipe-bound.
 // All eight waves multiply AND load (four pieces each per stage; the two waves of a SIMD alternate between the LDS-DMA
 // issue and their MFMA block); stores, LDS-DMA and loads share vmcnt, so the counted wait covers the stores in between.
-#ifndef GW_ABLATE
-#define GW_ABLATE 0                         /* diagnostic builds only (tools/exp_gen.py): 1 no stores, 2 no MFMAs, 3 no X streaming */
-#endif
 #define GW_ROWS 32                          /* X rows per stage */
 #define GW_STAGE (GW_ROWS * 1024)           /* bytes: K = 256 -> 8 lines = 1 KB per row */
 #define GW_STAGES 4
@@ -317,7 +314,7 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
         // issue comes AFTER the MFMA block: at the loop's back edge hipcc cannot match the pending LDS-DMAs with the slots they
         // target and drains vmcnt before the trip's first fragment read -- with the new pieces not yet issued that costs
         // nothing (the older ones have landed), with them issued it exposed one full memory latency every four stages
-        if (GW_ABLATE != 3 && u != 0 && st + 3 < nstages)
+        if (u != 0 && st + 3 < nstages)
             issue(st + 3, (u + 3) & (GW_STAGES - 1));
         const char *S = lds + u * GW_STAGE;
         gs_f4 acc[2][2];
@@ -335,17 +332,13 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
                 const gs_h8 xl = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + 4 + lk) ^ li) * 16));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    if (GW_ABLATE == 2) {
-                        asm volatile("" ::"v"(xh), "v"(xl), "v"(wl[t][ks]), "v"(wh[t][ks]));
-                        continue;
-                    }
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t][ks], xh, acc[t][j], 0, 0, 0);
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][ks], xl, acc[t][j], 0, 0, 0);
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][ks], xh, acc[t][j], 0, 0, 0);
                 }
             }
         }
-        if (GW_ABLATE != 3 && u == 0 && st + 3 < nstages)
+        if (u == 0 && st + 3 < nstages)
             issue(st + 3, 3);
         // C/D layout: col = li (X row), rows 4 lk + r = four consecutive features: one 16-byte store each
 #pragma unroll
@@ -355,10 +348,6 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
             for (int t = 0; t < 2; ++t) {
                 const int n = n0 + 16 * t + 4 * lk;
                 const gs_f4 v = acc[t][j] * g.alpha + bias4[t];
-                if (GW_ABLATE == 1) {
-                    asm volatile("" ::"v"(v));
-                    continue;
-                }
                 if (row < g.M) {
                     if (n + 3 < g.N) {
                         *reinterpret_cast<gs_f4 *>(g.out + (size_t)row * g.ld_out + n) = v;

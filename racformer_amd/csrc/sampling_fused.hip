@@ -33,9 +33,6 @@
 #ifndef S4D_WPS
 #define S4D_WPS 4 /* waves per SIMD the register allocator must allow */
 #endif
-#ifndef S4D_ABLATE
-#define S4D_ABLATE 0 /* diagnostic builds only (tools/exp_s4d.py): 1 no tap loads, 2 no keypoint arithmetic, 3 no output stores */
-#endif
 #define S4D_MAX_DEPTH 16
 #define S4D_MAX_CAMS 16
 
@@ -149,7 +146,7 @@ template <typename FT>
 __device__ __forceinline__ rac_f4 s4d_tap(const FT *base, int h, int w, int W, bool ok)
 {
     rac_f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok && S4D_ABLATE != 1)
+    if (ok)
         v = rac_ld4(base + ((size_t)h * W + w) * 64);
     return v;
 }
@@ -180,13 +177,6 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
     __syncthreads();
     for (int i = tid; i < nrows * P; i += 256) {
         const int r = i / P, p = i - r * P;
-        if (S4D_ABLATE == 2) {
-            sloc[i * 3] = 0.3f + 0.001f * (float)(i & 63); sloc[i * 3 + 1] = 0.4f; sloc[i * 3 + 2] = (float)(i % a.N);
-#pragma unroll
-            for (int l = 0; l < L; ++l)
-                sw[i * L + l] = 0.25f;
-            continue;
-        }
         s4d_keypoint<L>(a, sl2i, b, t, g, q0 + r, p, sloc + i * 3, sw + i * L);
         if (a.loc_out) {
             float *lo = a.loc_out + (((size_t)s * a.Q + q0 + r) * P + p) * 3;
@@ -261,9 +251,7 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
                 }
             }
         }
-        if (S4D_ABLATE == 3)
-            asm volatile("" ::"v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));
-        else if (act)
+        if (act)
             *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = acc;
     }
     }

@@ -8,7 +8,8 @@ import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = ["racformer_amd/csrc/sampling_fused.hip", "racformer_amd/csrc/bev_fused.hip", "racformer_amd/csrc/mixing.hip"]
+SOURCES = ["racformer_amd/csrc/sampling_fused.hip", "racformer_amd/csrc/bev_fused.hip", "racformer_amd/csrc/mixing.hip",
+           "racformer_amd/csrc/gemm_split.hip"]
 
 
 def load(d, counter):
@@ -26,7 +27,7 @@ def main():
     out = {"_source_sha": {rel: hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16] for rel in SOURCES
                            if os.path.exists(os.path.join(ROOT, rel))}}
     for k in sorted(set(fetch) | set(write)):
-        if not any(s in k for s in ("sampling4d", "bev_sampling", "msmv_fwd", "msda_fwd", "regroup", "sasa", "mixing", "conv3x3", "conv_pack", "rowgemm", "absmax", "genmix", "outproj")):
+        if not any(s in k for s in ("sampling4d", "bev_sampling", "msmv_fwd", "msda_fwd", "regroup", "sasa", "mixing", "conv3x3", "conv_pack", "rowgemm", "absmax", "generator", "gemm_split", "decode")):
             continue
         f = fetch.get(k, [])
         w = write.get(k, [])

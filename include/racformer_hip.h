@@ -98,6 +98,11 @@ int rac_msda_fwd(const void *value, const int64_t *shapes, const int64_t *starts
 int rac_regroup_fwd(const float *in, void *out, int B, int T, int N, int G, int C, int H, int W,
                     int out_dtype, void *stream);
 
+/* The same regroup for all L levels of the pyramid in ONE launch (16-byte accesses on both sides): ins / outs HOST arrays
+ * of L device pointers, hw HOST L x (H, W); C % 4 == 0 and H*W % 4 == 0 on every level. */
+int rac_regroup_multi_fwd(int L, const float *const *ins, void *const *outs, const int32_t *hw, int B, int T, int N, int G,
+                          int C, int out_dtype, void *stream);
+
 /* Per-query box constants shared by the fused sampling kernels: table[b,q] = (cx, cy, cz, w, l, h,
  * cos yaw, sin yaw) = decode_bbox(theta_d2xy_coods(query_bbox)) (models/bbox/utils.py:66-90), once per
  * query and layer instead of once per keypoint.  query_bbox device f32 [n,10], table device f32 [n,8]. */

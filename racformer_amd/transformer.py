@@ -1193,23 +1193,40 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
 
 
 def regroup_pyramid(mlvl_feats, num_cams, groups=4, out_dtype=torch.float32):
-    """racformer_transformer.py:112-124 as one HIP transpose per level:
-    [B,T*N,G*C,H,W] -> [B*T*G, N, H, W, C]."""
-    out = []
+    """racformer_transformer.py:112-124 as ONE HIP transpose launch over all levels:
+    [B,T*N,G*C,H,W] -> [B*T*G, N, H, W, C]  (rac_regroup_multi_fwd; levels whose sizes are not multiples of 4 go through
+    the scalar per-level kernel rac_regroup_fwd)."""
+    import ctypes
+    feats, outs, dims = [], [], None
     for feat in mlvl_feats:
         B, TN, GC, H, W = feat.shape
         if TN % num_cams != 0 or GC % groups != 0:
             raise RuntimeError("regroup_pyramid: expected [B, T*N, G*C, H, W]")
         N, T, C = num_cams, TN // num_cams, GC // groups
+        if dims is None:
+            dims = (B, T, N, C)
+        elif dims != (B, T, N, C):
+            raise RuntimeError("regroup_pyramid: levels must share B, T*N and G*C")
         feat = feat.float().contiguous()
         _lib.require_gpu(feat, what="regroup_pyramid")
-        dst = torch.empty(B * T * groups, N, H, W, C, device=feat.device, dtype=out_dtype)
-        code = _lib.RAC_F32 if out_dtype == torch.float32 else _lib.RAC_BF16
-        rc = _lib.lib().rac_regroup_fwd(_lib.ptr(feat), _lib.ptr(dst), B, T, N, groups, C, H, W, code,
-                                        _lib.stream_ptr())
-        _lib.check(rc, "rac_regroup_fwd")
-        out.append(dst)
-    return out
+        feats.append(feat)
+        outs.append(torch.empty(B * T * groups, N, H, W, C, device=feat.device, dtype=out_dtype))
+    if not feats:
+        return []
+    B, T, N, C = dims
+    code = _lib.RAC_F32 if out_dtype == torch.float32 else _lib.RAC_BF16
+    if C % 4 == 0 and all((f.shape[3] * f.shape[4]) % 4 == 0 for f in feats) and len(feats) <= 8:
+        L = len(feats)
+        ins = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+        dst = (ctypes.c_void_p * L)(*[o.data_ptr() for o in outs])
+        hw = (ctypes.c_int32 * (2 * L))(*[int(x) for f in feats for x in f.shape[3:5]])
+        _lib.check(_lib.lib().rac_regroup_multi_fwd(L, ins, dst, hw, B, T, N, groups, C, code, _lib.stream_ptr()), "rac_regroup_multi_fwd")
+        return outs
+    for feat, dst in zip(feats, outs):
+        H, W = feat.shape[3:5]
+        _lib.check(_lib.lib().rac_regroup_fwd(_lib.ptr(feat), _lib.ptr(dst), B, T, N, groups, C, H, W, code, _lib.stream_ptr()),
+                   "rac_regroup_fwd")
+    return outs
 
 
 class RaCFormerTransformerDecoder(nn.Module):

@@ -37,12 +37,12 @@ __device__ __forceinline__ float rg_wave_sum(float v)
 // EARLY: issue the first segment's weight loads above the prologue (best for the 228-workgroup launches, where one
 // workgroup per CU has to hide its own latencies); without it the kernel fits 128 VGPRs = 4 workgroups per CU, which is what
 // the wide layers (up to 1995 workgroups) need.
-template <int NSEG, int MT, bool EARLY, int NT>
+template <int NSEG, int MT, bool EARLY>
 __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, float *sX)
 {
     constexpr int K = 256 * NSEG, LD = K + 4, R = 16 * MT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = blockIdx.x * R, n0 = blockIdx.y * 64 * NT;
+    const int row0 = blockIdx.x * R, n0 = blockIdx.y * 64;
     const bool first_slice = blockIdx.y == 0;
     // GEMM roles (wave w owns columns n0 + 16w .. +15; lane (li, lk): A row li, B column li, k = 16u + 4lk + i).  The
     // first segment's weights do not depend on the prologue: their 16 loads per lane are issued before it.  Row tiles
@@ -160,82 +160,65 @@ __device__ __forceinline__ void rowgemm_body(const rac_rowgemm &d, int rows, flo
 
     // ---- GEMM ----
     // weights of one 256-wide segment = 16 loads of 16 bytes per lane, all issued before the segment's MFMAs; the
-    // next segment's loads are issued before the current segment's MFMAs (one memory latency per launch, not per step).
-    // NT > 1 (single-segment GEMMs with many output columns): the workgroup walks NT column tiles of 64 with ONE prologue --
-    // a quarter of the workgroups and of the redundant row-wise work of the 2189-wide sampling Linears -- and the next
-    // tile's weights are in flight under the current tile's MFMAs.
+    // next segment's loads are issued before the current segment's MFMAs (one memory latency per launch, not per step)
     const float *ap = sX + li * LD + 4 * lk;
     if (!EARLY) {
 #pragma unroll
         for (int u = 0; u < 16; ++u)
             bcur[u] = rac_ld4(bp + 16 * ((u + rot) & 15));
     }
-#pragma unroll 1
-    for (int nt = 0; nt < NT; ++nt) {
-        const int colt = col + 64 * nt;
-        if (NT > 1 && n0 + 64 * nt >= d.N)
-            break;                                   // (uniform per workgroup)
-        rg_f4 acc[MT][2];
+    rg_f4 acc[MT][2];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            acc[m][0] = acc[m][1] = (rg_f4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+        acc[m][0] = acc[m][1] = (rg_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sgm = 0; sgm < NSEG; ++sgm) {
-            if (sgm + 1 < NSEG) {
+    for (int sgm = 0; sgm < NSEG; ++sgm) {
+        if (sgm + 1 < NSEG) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    bnxt[u] = rac_ld4(bp + 256 * (sgm + 1) + 16 * ((u + rot) & 15));
-            } else if (NT > 1 && nt + 1 < NT) {
-                // next column tile's weights (NSEG == 1 here); rows past N re-read the last row, never stored
-                const int cn = colt + 64;
-                const float *bpn = d.w + (size_t)(cn < d.N ? cn : d.N - 1) * K + 4 * lk;
+            for (int u = 0; u < 16; ++u)
+                bnxt[u] = rac_ld4(bp + 256 * (sgm + 1) + 16 * ((u + rot) & 15));
+        }
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    bnxt[u] = rac_ld4(bpn + 16 * ((u + rot) & 15));
-            }
+        for (int u = 0; u < 16; ++u) {
+            const int ko = 256 * sgm + 16 * ((u + rot) & 15);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int ko = 256 * sgm + 16 * ((u + rot) & 15);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const rac_f4 a4 = *reinterpret_cast<const rac_f4 *>(ap + 16 * m * LD + ko);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bcur[u].x, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bcur[u].y, acc[m][1], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bcur[u].z, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bcur[u].w, acc[m][1], 0, 0, 0);
-                }
-            }
-            if (sgm + 1 < NSEG || (NT > 1 && nt + 1 < NT)) {
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    bcur[u] = bnxt[u];
+            for (int m = 0; m < MT; ++m) {
+                const rac_f4 a4 = *reinterpret_cast<const rac_f4 *>(ap + 16 * m * LD + ko);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bcur[u].x, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bcur[u].y, acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bcur[u].z, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bcur[u].w, acc[m][1], 0, 0, 0);
             }
         }
-        const int wr = colt < d.N ? colt : d.N - 1;
-        const float bv = d.b ? d.b[wr] : 0.f;
-        const bool relu = colt >= d.relu_from;
+        if (sgm + 1 < NSEG) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 16 * m + 4 * lk + r;
-                float v = (acc[m][0][r] + acc[m][1][r]) + bv;
-                if (relu)
-                    v = fmaxf(v, 0.f);
-                if (row < rows && colt < d.N)
-                    d.out[(size_t)row * d.ld_out + colt] = v;
-            }
+            for (int u = 0; u < 16; ++u)
+                bcur[u] = bnxt[u];
+        }
     }
+    const float bv = d.b ? d.b[wrow] : 0.f;
+    const bool relu = col >= d.relu_from;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 16 * m + 4 * lk + r;
+            float v = (acc[m][0][r] + acc[m][1][r]) + bv;
+            if (relu)
+                v = fmaxf(v, 0.f);
+            if (row < rows && col < d.N)
+                d.out[(size_t)row * d.ld_out + col] = v;
+        }
 }
 
-template <int NSEG, int MT, bool EARLY, int NT = 1>
-__global__ __launch_bounds__(256, NT > 1 ? 3 : (EARLY ? 2 : 4)) void rowgemm_kernel(const RowGemmArgs a)
+template <int NSEG, int MT, bool EARLY>
+__global__ __launch_bounds__(256, EARLY ? 2 : 4) void rowgemm_kernel(const RowGemmArgs a)
 {
     extern __shared__ float smem[];
     const rac_rowgemm &d = a.d[blockIdx.z];
-    if ((int)blockIdx.y * 64 * NT >= d.N)
+    if ((int)blockIdx.y * 64 >= d.N)
         return;   // (uniform per workgroup: batched GEMMs may have different widths)
-    rowgemm_body<NSEG, MT, EARLY, NT>(d, a.rows, smem);
+    rowgemm_body<NSEG, MT, EARLY>(d, a.rows, smem);
 }
 
 extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void *stream)
@@ -267,15 +250,9 @@ extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void
     a.rows = rows;
     const int R = 16;
     const size_t lds = (size_t)R * (256 * max_seg + 4) * sizeof(float);
-    // single-segment GEMMs with many columns: 4 (N >= 768) or 2 (N >= 512) column tiles of 64 per workgroup
-    const int NT = max_seg == 1 ? (max_n >= 768 ? 4 : (max_n >= 512 ? 2 : 1)) : 1;
-    const dim3 grid((rows + R - 1) / R, (max_n + 64 * NT - 1) / (64 * NT), num);
+    const dim3 grid((rows + R - 1) / R, (max_n + 63) / 64, num);
     hipStream_t st = (hipStream_t)stream;
-    if (NT == 4)
-        hipLaunchKernelGGL((rowgemm_kernel<1, 1, true, 4>), grid, dim3(256), lds, st, a);
-    else if (NT == 2)
-        hipLaunchKernelGGL((rowgemm_kernel<1, 1, true, 2>), grid, dim3(256), lds, st, a);
-    else if (max_seg == 1 && (long)grid.x * grid.y * grid.z > 512)
+    if (max_seg == 1 && (long)grid.x * grid.y * grid.z > 512)
         hipLaunchKernelGGL((rowgemm_kernel<1, 1, false>), grid, dim3(256), lds, st, a);   // many workgroups: occupancy first
     else if (max_seg == 1)
         hipLaunchKernelGGL((rowgemm_kernel<1, 1, true>), grid, dim3(256), lds, st, a);

@@ -15,7 +15,8 @@ else:
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "regroup" in r["Kernel_Name"]]
-starts = idx[::4]
+per_fwd = 1 if any("regroup_multi" in r["Kernel_Name"] for r in rows) else 4     # regroup launches per forward
+starts = idx[::per_fwd]
 a, b = starts[-back - 1], starts[-back]
 t0 = prev = int(rows[a]["Start_Timestamp"])
 tot = gap = 0

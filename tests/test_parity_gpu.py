@@ -84,6 +84,31 @@ def test_decoder_f8_vs_oracle_unseen_seed():
     decoder_parity(cls, box, ocls, obox, what="f8 seed 17 vs oracle")
 
 
+@pytest.mark.parametrize("name,cfg", [("decoder_f8.npz", syn.F8), ("decoder_f8_3cam.npz", syn.F8_3CAM)])
+def test_decoder_bf16_feature_storage_measured_gap(golden_dir, name, cfg):
+    """BASELINE configs 3 / 5 name bf16.  The gather kernels take a bf16 pyramid (`decoder.feature_dtype = torch.bfloat16`: half
+    the sampling kernel's bytes), and this is what that costs against the reference's fp32 CPU forward, as a test with its
+    own stated bound rather than prose: one layer stays inside north_star's tolerance (boxes < 1e-3, argmax identical --
+    measured 7.3e-4 / 6.3e-4 at most), six free-running layers do not (measured at layer 5: median 9.6e-4 / 3.1e-4,
+    433 / 241 of 900 queries over 1e-3, 3 / 2 argmax flips), which is why the default and the benchmark keep fp32 storage."""
+    g = np.load(os.path.join(golden_dir, name))
+    seed, wseed = int(g["seed"]), int(g["weight_seed"])
+    tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+    syn.fill_params(tr, wseed)
+    tr = tr.to(DEV)
+    tr.decoder.feature_dtype = torch.bfloat16
+    qb, qf = syn.make_queries(cfg, seed)
+    with torch.no_grad():
+        cls, box = tr(qb.to(DEV), qf.to(DEV), [f.to(DEV) for f in syn.make_pyramid(cfg, seed)],
+                      syn.make_bev(cfg, seed, 0).to(DEV), syn.make_bev(cfg, seed, 1).to(DEV), None, syn.make_img_metas(cfg))
+    eb = (box.cpu() - t(g["box"])).abs().amax(-1)[:, 0]
+    mism = (cls.cpu().argmax(-1) != t(g["cls"]).argmax(-1))[:, 0]
+    print("bf16 features:", [f"L{l} p50 {eb[l].median():.1e} max {eb[l].max():.1e} argmax {int(mism[l].sum())}" for l in range(eb.shape[0])])
+    assert eb[0].max().item() < 1e-3 and int(mism[0].sum()) == 0                 # one layer: inside the tolerance
+    assert eb[-1].median().item() < 2e-3 and int(mism[-1].sum()) <= 9            # six layers: bounded, but outside it
+    assert int((eb[-1] > 1e-3).sum()) > 9, "bf16 storage now meets the tolerance: make it the default and update DESIGN"
+
+
 # ------------------------------------------------------------------------------------------------ teacher forcing
 def test_decoder_f8_teacher_forced(golden_dir):
     """Every decoder layer (each d_region) fed the reference's own (query_bbox, query_feat): all 900 queries within 1e-4 on

@@ -308,10 +308,13 @@ __device__ __forceinline__ void mix_split_bf16(float v, __bf16 &t1, __bf16 &t2, 
 }
 
 #define MIXH_XS 80    /* f16 row stride of the x images  (160 B) */
-#define MIXH_SS 112   /* f16 row stride of the S images  (224 B) */
+#define MIXH_SS 104   /* f16 row stride of the S images  (208 B) */
 #define MIXH_X_BYTES (3 * MIX_PMAX * MIXH_XS * 2)   /* three bf16 terms: 46080 */
-#define MIXH_S_BYTES (2 * 64 * MIXH_SS * 2)         /* hi + lo of one 64-row half: 28672 */
-#define MIXH_LDS_BYTES (MIXH_X_BYTES + MIXH_S_BYTES + 64)
+#define MIXH_S_BYTES (2 * MIX_OUT * MIXH_SS * 2)    /* hi + lo of all 128 rows: 53248 */
+/* the x images (step 1), the S images (step 2) and the output tile (epilogue) take turns in ONE region: 53 KB, so three
+   workgroups share a CU's 160 KB */
+#define MIXH_REGION_BYTES (MIXH_S_BYTES > MIXH_X_BYTES ? MIXH_S_BYTES : MIXH_X_BYTES)
+#define MIXH_LDS_BYTES (MIXH_REGION_BYTES + 64)
 
 __device__ __forceinline__ void mix_split4(const rac_f4 v, float scale, rac_h4 &hi, rac_h4 &lo)
 {
@@ -321,18 +324,16 @@ __device__ __forceinline__ void mix_split4(const rac_f4 v, float scale, rac_h4 &
     rac_split_f16(v.w * scale, hi.w, lo.w);
 }
 
-__global__ __launch_bounds__(256, 2) void mixing_c64_f16x3_kernel(const MixArgs a)
+__global__ __launch_bounds__(256, 3) void mixing_c64_f16x3_kernel(const MixArgs a)
 {
     extern __shared__ float smem[];
     unsigned char *lds = reinterpret_cast<unsigned char *>(smem);
     __bf16 *sX1 = reinterpret_cast<__bf16 *>(lds);                         // [96][80] x 3 terms
     __bf16 *sX2 = sX1 + MIX_PMAX * MIXH_XS;
     __bf16 *sX3 = sX2 + MIX_PMAX * MIXH_XS;
-    _Float16 *sS0h = reinterpret_cast<_Float16 *>(lds + MIXH_X_BYTES);     // [64][112]  S rows 0..63
-    _Float16 *sS0l = sS0h + 64 * MIXH_SS;
-    _Float16 *sS1h = reinterpret_cast<_Float16 *>(lds);                    // S rows 64..127 reuse the x region
-    _Float16 *sS1l = sS1h + 64 * MIXH_SS;
-    float *red = reinterpret_cast<float *>(lds + MIXH_X_BYTES + MIXH_S_BYTES);
+    _Float16 *sSh = reinterpret_cast<_Float16 *>(lds);                     // [128][104] hi, then lo: over the x images
+    _Float16 *sSl = sSh + MIX_OUT * MIXH_SS;
+    float *red = reinterpret_cast<float *>(lds + MIXH_REGION_BYTES);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -418,9 +419,6 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_f16x3_kernel(const MixArgs 
             bM2[ks][j] = t2;
             bM3[ks][j] = t3;
         }
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-        store_S(sS0h, sS0l, k, vs0[k]);
     __syncthreads();
 
     // ---- step 1: Y = x @ M, wave w -> columns 16w.. ------------------------------------------------------------
@@ -461,10 +459,12 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_f16x3_kernel(const MixArgs 
         }
     const float rstd1 = 1.f / sqrtf(mix_block_sum(part, red, wave, lane) / n1 + a.eps);
     // (both block sums end with barriers: every wave is past its last read of the x images, so the region can
-    //  take S rows 64..127 now)
+    //  take the S images now; S stayed in registers through step 1)
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
-        store_S(sS1h, sS1l, k, vs1[k]);
+    for (int k = 0; k < 6; ++k) {
+        store_S(sSh, sSl, k, vs0[k]);
+        store_S(sSh + 64 * MIXH_SS, sSl + 64 * MIXH_SS, k, vs1[k]);
+    }
     // Y = relu(LN(.)) -> B fragments of the second product, in registers
     mix_h8 bYh[3], bYl[3];
 #pragma unroll
@@ -480,19 +480,18 @@ __global__ __launch_bounds__(256, 2) void mixing_c64_f16x3_kernel(const MixArgs 
                 bYh[t][4 * h + r] = yh;
                 bYl[t][4 * h + r] = yl;
             }
-    __syncthreads();   // S rows 64..127 visible
+    __syncthreads();   // S visible
 
     // ---- step 2: Z = S @ Y ---------------------------------------------------------------------------------------
     mix_f4 acc2[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         acc2[m] = (mix_f4){0.f, 0.f, 0.f, 0.f};
-        const _Float16 *sh = m < 4 ? sS0h : sS1h, *sl = m < 4 ? sS0l : sS1l;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const int off = (16 * (m & 3) + li) * MIXH_SS + 32 * t + 8 * lk;
-            const mix_h8 ah = *reinterpret_cast<const mix_h8 *>(sh + off);
-            const mix_h8 al = *reinterpret_cast<const mix_h8 *>(sl + off);
+            const int off = (16 * m + li) * MIXH_SS + 32 * t + 8 * lk;
+            const mix_h8 ah = *reinterpret_cast<const mix_h8 *>(sSh + off);
+            const mix_h8 al = *reinterpret_cast<const mix_h8 *>(sSl + off);
             acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bYh[t], acc2[m], 0, 0, 0);
             acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bYl[t], acc2[m], 0, 0, 0);
             acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bYh[t], acc2[m], 0, 0, 0);
@@ -554,9 +553,9 @@ extern "C" int rac_mixing_fwd(const float *x, const float *params, float param_s
         attr_set = true;
     }
     if (mfma_mode == RAC_MIX_F16X3) {
-        static_assert(MIXH_X_BYTES >= MIXH_S_BYTES, "S rows 64..127 reuse the x region");
-        static_assert(2 * MIXH_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-        static_assert(MIXH_X_BYTES + MIXH_S_BYTES >= MIX_OUT * MIX_C * 4, "output tile must fit the x | S region");
+        static_assert(3 * MIXH_LDS_BYTES <= 160 * 1024, "three workgroups per CU");
+        static_assert(MIXH_REGION_BYTES >= MIX_OUT * MIX_C * 4, "output tile must fit the shared region");
+        static_assert(MIXH_SS >= MIX_PMAX + 8 && (MIXH_SS * 2) % 16 == 0, "S row stride");
         static bool attr16_set = false;
         if (!attr16_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mixing_c64_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MIXH_LDS_BYTES);

@@ -46,8 +46,23 @@ struct BevArgs {
     int B, T, Q, heads, NP, D, P, H, W;
     int ld_off, ld_ray, ld_scale, ld_queue;  // row strides (floats): slices of one fused GEMM output
     int blocks_per_b;
+    unsigned value_bytes;    // size of one stream's value buffer (the buffer descriptor's range)
+    int list_len;            // entries of a 16-lane group's tap list
+    int list_holes;          // 1: some list slots have no keypoint (filled with zero-weight outside taps)
     int xcd_remap;           // 1: blocks that share an XCD (blockIdx & 7) take a contiguous range of items (speed only)
 };
+
+// polar jitter of a keypoint (racformer_transformer.py:512-522 through models/bbox/utils.py:84-106): (ex, ey) metres from the
+// map centre -> (dist, theta), dist += doff, back to the normalised map.  (Scaling the unit vector (ex, ey) / r directly
+// would skip atan2f / fmodf / cosf / sinf; measured: under 1 us of 81 per launch -- not worth leaving the reference's chain.)
+__device__ __forceinline__ void bev_polar_jitter(float ex, float ey, float doff, float *loc2)
+{
+    const float dist = sqrtf(ex * ex + ey * ey) / 65.0f + doff;
+    const float th = fmodf(atan2f(ey, ex) + BEV_TWO_PI, BEV_TWO_PI) / BEV_TWO_PI;
+    const float ang = th * BEV_TWO_PI, rad = dist * 65.0f;
+    loc2[0] = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f);
+    loc2[1] = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f);
+}
 
 __device__ __forceinline__ void bev_keypoint(const BevArgs &a, const BevStream &s, int bq, int tq, int q, int h, int p, float *loc2)
 {
@@ -68,27 +83,41 @@ __device__ __forceinline__ void bev_keypoint(const BevArgs &a, const BevStream &
     py -= qb[9] * td;
     const float nx = (px - a.pc[0]) / sx, ny = (py - a.pc[1]) / sy;
     const float ex = nx * 102.4f - 51.2f, ey = ny * 102.4f - 51.2f;
-    float dist = sqrtf(ex * ex + ey * ey) / 65.0f;
-    const float th = fmodf(atan2f(ey, ex) + BEV_TWO_PI, BEV_TWO_PI) / BEV_TWO_PI;
     const int dd = p % a.D;
     const float sg = 1.f / (1.f + expf(-s.ray[((size_t)bq * a.Q + q) * a.ld_ray + dd]));
-    dist += a.depth_base[dd] + (sg * 2.f - 1.f) * a.d_region / (float)a.D / 2.f;
-    const float ang = th * BEV_TWO_PI, rad = dist * 65.0f;
-    loc2[0] = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f);
-    loc2[1] = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f);
+    bev_polar_jitter(ex, ey, a.depth_base[dd] + (sg * 2.f - 1.f) * a.d_region / (float)a.D / 2.f, loc2);
 }
 
-template <typename FT>
-__device__ __forceinline__ rac_f4 bev_tap(const FT *base, long pix, int stride, bool ok)
-{
-    rac_f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok)
-        v = rac_ld4(base + pix * stride);
-    return v;
-}
-
+#ifndef BEV_U
+#define BEV_U 4    /* keypoints per gather batch (4 taps each in flight) */
+#endif
+#ifndef BEV_OCC
+#define BEV_OCC 4  /* workgroups per CU the register budget is cut for */
+#endif
 #define BEV_GI 4   /* items (b,q,head) per workgroup */
 #define BEV_TS 4   /* point subsets per item: 16-lane group (k, ts) handles points ts, ts+4, ... of every frame */
+#define BEV_TAP_OUTSIDE 0x80000000u   /* tap offset past the end of the value buffer: the buffer load returns zeros */
+
+typedef float bev_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int bev_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int bev_u4 __attribute__((ext_vector_type(4)));
+
+// Four channels of one tap through a buffer descriptor: the range check of the descriptor stands in for the four
+// branches of the bilinear footprint (a tap outside the map carries the offset BEV_TAP_OUTSIDE and reads as zero).
+template <typename FT>
+__device__ __forceinline__ rac_f4 bev_tap(__amdgpu_buffer_rsrc_t rsrc, unsigned off);
+template <>
+__device__ __forceinline__ rac_f4 bev_tap<float>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+{
+    return __builtin_bit_cast(rac_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ rac_f4 bev_tap<unsigned short>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+{
+    const bev_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);    // 4 x bf16
+    return (rac_f4){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                    __uint_as_float(r.y & 0xffff0000u)};
+}
 
 // per-(t,p) half of the keypoint chain for B==1: warp the T-invariant base point, polar jitter.
 __device__ __forceinline__ void bev_warp(const BevArgs &a, float px, float py, float vx, float vy, float td,
@@ -99,22 +128,35 @@ __device__ __forceinline__ void bev_warp(const BevArgs &a, float px, float py, f
     py -= vy * td;
     const float nx = (px - a.pc[0]) / sx, ny = (py - a.pc[1]) / sy;
     const float ex = nx * 102.4f - 51.2f, ey = ny * 102.4f - 51.2f;
-    const float dist = sqrtf(ex * ex + ey * ey) / 65.0f + doff;
-    const float th = fmodf(atan2f(ey, ex) + BEV_TWO_PI, BEV_TWO_PI) / BEV_TWO_PI;
-    const float ang = th * BEV_TWO_PI, rad = dist * 65.0f;
-    loc2[0] = fminf(fmaxf((51.2f + rad * cosf(ang)) / 102.4f, 0.f), 1.f);
-    loc2[1] = fminf(fmaxf((51.2f + rad * sinf(ang)) / 102.4f, 0.f), 1.f);
+    bev_polar_jitter(ex, ey, doff, loc2);
+}
+
+__device__ __forceinline__ float bev_wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float bev_wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m, 64);
+    return v;
 }
 
 template <typename FT>
-__global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs a)
+__global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const BevArgs a)
 {
     extern __shared__ float smem[];
     const BevStream &s = a.s[blockIdx.y];
     const int tid = threadIdx.x;
     const int c4 = tid & 15, grp = tid >> 4;
-    const int k = grp >> 2, ts = grp & 3;       // item within the workgroup, frame subset
+    const int k = grp >> 2, ts = grp & 3;       // item within the workgroup, point subset
     const int T = a.T, P = a.P, TP = a.T * a.P, D = a.D;
+    const int npp = (P + BEV_TS - 1) / BEV_TS;  // points of a subset per frame (the last subsets may hold one less)
+    const int Lg = a.list_len;                  // entries of a group's tap list: T * npp rounded up to BEV_U
 
     const int per_b = a.Q * a.heads;
     int bid = blockIdx.x;
@@ -128,75 +170,102 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
     const int i0 = (bid % a.blocks_per_b) * BEV_GI;
     const int nitems = min(BEV_GI, per_b - i0);
 
-    float *sloc = smem;                        // [GI][T][P][2]
+    // tap lists, one per 16-lane group and in the order the group walks them (frame-major): [GI][TS][Lg][8] =
+    // 4 tap byte offsets into the value buffer (BEV_TAP_OUTSIDE = outside the map) + 4 tap weights
+    float *stab = smem;
+    float *spart = stab + BEV_GI * BEV_TS * Lg * 8;  // [GI][TS][64] partial sums
     const int Tw = a.B > 1 ? T : 1;            // B > 1: the point weights depend on the frame (paired batch, quirk Q2)
-    float *sattn = sloc + BEV_GI * TP * 2;     // [GI][Tw][P]
+    float *sattn = spart + BEV_GI * BEV_TS * 64;     // [GI][Tw][P]
     float *sq = sattn + BEV_GI * Tw * P;       // [GI][T]
     float *sbase = sq + BEV_GI * T;            // [GI][P][2]  T-invariant base points (B==1)
     float *sdoff = sbase + BEV_GI * P * 2;     // [GI][D]
-    float *spart = sdoff + BEV_GI * BEV_MAX_DEPTH;  // [GI][TS][64] partial sums
-    float *stab = spart + BEV_GI * BEV_TS * 64;     // [GI][T][P][8]: 4 tap pixel indices (int, -1 = outside) + 4 tap weights
+    float *svel = sdoff + BEV_GI * BEV_MAX_DEPTH;    // [GI][2] query velocity, then [T] time_diff of batch b (B==1)
+    float *std_ = svel + BEV_GI * 2;
 
-    // phase A: T-invariant pieces.  threads [0, GI*P): base points; [128,128+GI*D): depth offsets;
-    // [192,192+GI): softmaxes of the point weights and of the frame weights.
-    if (tid < nitems * P && a.B == 1) {
+    // list slots no keypoint fills (P not a multiple of 4, T * npp not a multiple of BEV_U): outside, weight 0
+    if (a.list_holes) {
+        for (int i = tid; i < BEV_GI * BEV_TS * Lg * 2; i += 256) {
+            const unsigned fill = (i & 1) ? 0u : BEV_TAP_OUTSIDE;
+            reinterpret_cast<bev_u4 *>(stab)[i] = (bev_u4){fill, fill, fill, fill};
+        }
+    }
+
+    // phase A: T-invariant pieces.  threads [0, GI*P): base points; [128,128+GI*D): depth offsets; wave k: the two
+    // softmaxes of item k (point weights, frame weights) across its lanes.  Every role issues its global loads first --
+    // one round trip for the whole phase instead of one per role (and per softmax term).
+    const bool r_base = tid < nitems * P && a.B == 1;
+    const bool r_doff = tid >= 128 && tid < 128 + nitems * D && a.B == 1;
+    const int wk = tid >> 6, ln = tid & 63;
+    const bool r_soft = wk < nitems;
+    float g_bt[8], g_o0 = 0.f, g_o1 = 0.f, g_ray = 0.f, g_q = -INFINITY, g_lg = -INFINITY;
+    if (r_base) {
         const int kk = tid / P, p = tid - kk * P;
         const int it = i0 + kk, q = it / a.heads, h = it % a.heads;
         const float *bt = a.box + ((size_t)b * a.Q + q) * 8;
         const float *o = s.off + ((size_t)b * a.Q + q) * a.ld_off + ((size_t)h * P + p) * 2;
-        const float dx = bt[3] * o[0], dy = bt[4] * o[1];
-        sbase[tid * 2] = bt[0] + (dx * bt[6] - dy * bt[7]);
-        sbase[tid * 2 + 1] = bt[1] + (dx * bt[7] + dy * bt[6]);
+        const rac_f4 b0 = rac_ld4(bt), b1 = rac_ld4(bt + 4);
+        g_bt[0] = b0.x; g_bt[1] = b0.y; g_bt[3] = b0.w; g_bt[4] = b1.x; g_bt[6] = b1.z; g_bt[7] = b1.w;
+        g_o0 = o[0]; g_o1 = o[1];
     }
-    if (tid >= 128 && tid < 128 + nitems * D && a.B == 1) {
+    if (r_doff) {
         const int kk = (tid - 128) / D, dd = (tid - 128) - kk * D;
         const int q = (i0 + kk) / a.heads;
-        const float sg = 1.f / (1.f + expf(-s.ray[((size_t)b * a.Q + q) * a.ld_ray + dd]));
+        g_ray = s.ray[((size_t)b * a.Q + q) * a.ld_ray + dd];
+    }
+    if (r_soft) {
+        const int it = i0 + wk, q = it / a.heads, h = it % a.heads;
+        if (ln < T)
+            g_q = s.queue[((size_t)b * a.Q + q) * a.ld_queue + ln];
+        if (a.B == 1 && ln < P)
+            g_lg = s.scale[((size_t)b * a.Q + q) * a.ld_scale + (size_t)h * P + ln];
+    }
+    // velocity of each item's query and the frame times (phase B reads them per keypoint): threads 224.. / 192..
+    if (a.B == 1 && tid >= 224 && tid < 224 + nitems * 2) {
+        const int kk = (tid - 224) >> 1;
+        svel[tid - 224] = a.qbox[((size_t)b * a.Q + (i0 + kk) / a.heads) * 10 + 8 + ((tid - 224) & 1)];
+    }
+    if (a.B == 1 && tid >= 192 && tid < 192 + min(T, 32))
+        for (int t = tid - 192; t < T; t += 32)
+            std_[t] = a.time_diff[b * T + t];
+    if (r_base) {
+        const float dx = g_bt[3] * g_o0, dy = g_bt[4] * g_o1;
+        sbase[tid * 2] = g_bt[0] + (dx * g_bt[6] - dy * g_bt[7]);
+        sbase[tid * 2 + 1] = g_bt[1] + (dx * g_bt[7] + dy * g_bt[6]);
+    }
+    if (r_doff) {
+        const int kk = (tid - 128) / D, dd = (tid - 128) - kk * D;
+        const float sg = 1.f / (1.f + expf(-g_ray));
         sdoff[kk * BEV_MAX_DEPTH + dd] = a.depth_base[dd] + (sg * 2.f - 1.f) * a.d_region / (float)D / 2.f;
     }
-    if (tid >= 192 && tid < 192 + nitems) {
-        const int kk = tid - 192;
-        const int it = i0 + kk, q = it / a.heads, h = it % a.heads;
-        const float *qg = s.queue + ((size_t)b * a.Q + q) * a.ld_queue;
-        float mx = qg[0];
-        for (int t = 1; t < T; ++t)
-            mx = fmaxf(mx, qg[t]);
-        float sum = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float e = expf(qg[t] - mx);
-            sq[kk * T + t] = e;
-            sum += e;
-        }
-        for (int t = 0; t < T; ++t)
-            sq[kk * T + t] /= sum;
+    if (r_soft) {                                      // wave-uniform
+        const float mq = bev_wave_max(g_q);
+        const float eq = ln < T ? expf(g_q - mq) : 0.f;
+        const float sumq = bev_wave_sum(eq);
+        if (ln < T)
+            sq[wk * T + ln] = eq / sumq;
         if (a.B == 1) {
-            const float *lg = s.scale + ((size_t)b * a.Q + q) * a.ld_scale + (size_t)h * P;
-            float m2 = lg[0];
-            for (int p = 1; p < P; ++p)
-                m2 = fmaxf(m2, lg[p]);
-            float s2 = 0.f;
-            for (int p = 0; p < P; ++p) {
-                const float e = expf(lg[p] - m2);
-                sattn[kk * P + p] = e;
-                s2 += e;
-            }
-            for (int p = 0; p < P; ++p)
-                sattn[kk * P + p] /= s2;
+            const float ml = bev_wave_max(g_lg);
+            const float el = ln < P ? expf(g_lg - ml) : 0.f;
+            const float suml = bev_wave_sum(el);
+            if (ln < P)
+                sattn[wk * P + ln] = el / suml;
         }
     }
     __syncthreads();
     // phase B: per-frame keypoints
+    const int H = a.H, W = a.W;
+    const unsigned pix_bytes = (unsigned)(a.heads * 64 * sizeof(FT));   // one pixel: heads x 64 channels
     for (int i = tid; i < nitems * TP; i += 256) {
         const int kk = i / TP, r = i - kk * TP, t = r / P, p = r - t * P;
         const int it = i0 + kk, q = it / a.heads, h = it % a.heads;
+        float loc[2];
         if (a.B == 1) {
-            const float *qb = a.qbox + ((size_t)b * a.Q + q) * 10;
-            bev_warp(a, sbase[(kk * P + p) * 2], sbase[(kk * P + p) * 2 + 1], qb[8], qb[9], a.time_diff[b * T + t],
-                     sdoff[kk * BEV_MAX_DEPTH + p % D], sloc + i * 2);
+            bev_warp(a, sbase[(kk * P + p) * 2], sbase[(kk * P + p) * 2 + 1], svel[kk * 2], svel[kk * 2 + 1], std_[t],
+                     sdoff[kk * BEV_MAX_DEPTH + p % D], loc);
         } else {
             const int fi = b * T + t;                // value frame index
             const int bq = fi % a.B, tq = fi / a.B;  // whose locations it is paired with (quirk Q2)
-            bev_keypoint(a, s, bq, tq, q, h, p, sloc + i * 2);
+            bev_keypoint(a, s, bq, tq, q, h, p, loc);
             // point softmax of the paired batch b' (rare path: every thread redoes the P-term reduction)
             const float *lg = s.scale + ((size_t)bq * a.Q + q) * a.ld_scale + (size_t)h * P;
             float wmax = lg[0];
@@ -208,78 +277,70 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
             sattn[(kk * T + t) * P + p] = expf(lg[p] - wmax) / s2;
         }
         {
-            // Tap table of this keypoint: bilinear footprint (Deformable-DETR semantics, align_corners=False, zero padding),
+            // Tap list entry of this keypoint: bilinear footprint (Deformable-DETR semantics, align_corners=False, zero padding),
             // the point's attention weight and the frame weight folded into the four tap weights.  Computed once here
             // (one thread per keypoint) instead of by each of the 16 lanes that later gather the point.
             const float wgt = sattn[(kk * Tw + (a.B > 1 ? t : 0)) * P + p] * sq[kk * T + t];
-            const int Hh = a.H, Ww = a.W;
-            const float h_im = sloc[i * 2 + 1] * (float)Hh - 0.5f, w_im = sloc[i * 2] * (float)Ww - 0.5f;
-            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)Hh && w_im < (float)Ww;
+            const float h_im = loc[1] * (float)H - 0.5f, w_im = loc[0] * (float)W - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
             const float hf = floorf(h_im), wf = floorf(w_im);
             const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
             const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-            const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= Hh - 1;
-            const bool l_ok = w_low >= 0, r_ok = w_high <= Ww - 1;
-            int *ti = reinterpret_cast<int *>(stab + i * 8);
-            ti[0] = t_ok && l_ok ? h_low * Ww + w_low : -1;
-            ti[1] = t_ok && r_ok ? h_low * Ww + w_high : -1;
-            ti[2] = b_ok && l_ok ? h_high * Ww + w_low : -1;
-            ti[3] = b_ok && r_ok ? h_high * Ww + w_high : -1;
-            stab[i * 8 + 4] = hh * hw * wgt;
-            stab[i * 8 + 5] = hh * lw * wgt;
-            stab[i * 8 + 6] = lh * hw * wgt;
-            stab[i * 8 + 7] = lh * lw * wgt;
+            const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
+            const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+            // byte offset of (frame b*T+t, pixel 0, head h, channel 0) in the value buffer
+            const unsigned fbase = ((unsigned)(b * T + t) * (unsigned)(H * W) * (unsigned)a.heads + (unsigned)h) * (unsigned)(64 * sizeof(FT));
+            float *e = stab + (((kk * BEV_TS + (p & (BEV_TS - 1))) * Lg) + t * npp + (p >> 2)) * 8;
+            static_assert(BEV_TS == 4, "point subset = p & 3, slot = p >> 2");
+            bev_u4 off;
+            off.x = t_ok && l_ok ? fbase + (unsigned)(h_low * W + w_low) * pix_bytes : BEV_TAP_OUTSIDE;
+            off.y = t_ok && r_ok ? fbase + (unsigned)(h_low * W + w_high) * pix_bytes : BEV_TAP_OUTSIDE;
+            off.z = b_ok && l_ok ? fbase + (unsigned)(h_high * W + w_low) * pix_bytes : BEV_TAP_OUTSIDE;
+            off.w = b_ok && r_ok ? fbase + (unsigned)(h_high * W + w_high) * pix_bytes : BEV_TAP_OUTSIDE;
+            *reinterpret_cast<bev_u4 *>(e) = off;
+            *reinterpret_cast<rac_f4 *>(e + 4) = (rac_f4){hh * hw * wgt, hh * lw * wgt, lh * hw * wgt, lh * lw * wgt};
         }
         if (s.loc_out) {
             float *lo = s.loc_out + (((((size_t)b * a.Q + q) * a.heads + h) * T + t) * P + p) * 2;
-            lo[0] = sloc[i * 2];
-            lo[1] = sloc[i * 2 + 1];
+            lo[0] = loc[0];
+            lo[1] = loc[1];
         }
     }
     __syncthreads();
 
-    rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    // phase C: a group walks its list (frame-major: the chip works on (nearly) one frame at a time, which the L2s /
+    // Infinity Cache hold better than all of them), BEV_U keypoints = 4 * BEV_U taps in flight.  Per tap: one add for
+    // the lane's channel offset, one buffer load, two packed FMAs -- the gather runs at the L1 rate, not the VALU's.
+    bev_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     const bool live = k < nitems;
-    const int it = i0 + (live ? k : 0), h = it % a.heads;
-    const int H = a.H, W = a.W, stride = a.heads * 64;
-    const long keys = (long)H * W;
     if (live) {
-        // A group owns the points p = ts, ts+4, ... of every frame and walks its (frame, point) pairs frame-major, four
-        // at a time (16 taps in flight, every batch full): all groups move through the frames in the same order, so the
-        // chip works on (nearly) one 16.8 MB frame at a time, which the L2s / Infinity Cache hold better than four.
-        const int npp = (P - ts + BEV_TS - 1) / BEV_TS;   // this subset's points per frame
-        const int total = T * npp;
-        for (int j0 = 0; j0 < total; j0 += 4) {
-            rac_f4 v[4][4];
-            float tw[4][4];
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.value), 0, a.value_bytes, 0x00020000);
+        const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
+        const float *e = stab + (k * BEV_TS + ts) * Lg * 8;          // same address for the 16 lanes of the group
+        for (int j0 = 0; j0 < Lg; j0 += BEV_U) {
+            rac_f4 v[BEV_U][4], tw[BEV_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                const bool act = j < total;
-                const int jj = act ? j : total - 1;
-                const int t = jj / npp, p = ts + BEV_TS * (jj - t * npp);
-                const FT *base = (const FT *)s.value + ((size_t)(b * T + t) * keys * a.heads + h) * 64 + c4 * 4;
-                const float *e = stab + (k * TP + t * P + p) * 8;          // same address for the 16 lanes of the group
-                const rac_f4 ei = *reinterpret_cast<const rac_f4 *>(e), ew = *reinterpret_cast<const rac_f4 *>(e + 4);
-                const int o0 = __float_as_int(ei.x), o1 = __float_as_int(ei.y), o2 = __float_as_int(ei.z), o3 = __float_as_int(ei.w);
-                v[u][0] = bev_tap(base, (long)o0, stride, act && o0 >= 0);
-                v[u][1] = bev_tap(base, (long)o1, stride, act && o1 >= 0);
-                v[u][2] = bev_tap(base, (long)o2, stride, act && o2 >= 0);
-                v[u][3] = bev_tap(base, (long)o3, stride, act && o3 >= 0);
-                tw[u][0] = act ? ew.x : 0.f;
-                tw[u][1] = act ? ew.y : 0.f;
-                tw[u][2] = act ? ew.z : 0.f;
-                tw[u][3] = act ? ew.w : 0.f;
+            for (int u = 0; u < BEV_U; ++u) {
+                const bev_u4 o = *reinterpret_cast<const bev_u4 *>(e + (j0 + u) * 8);
+                tw[u] = *reinterpret_cast<const rac_f4 *>(e + (j0 + u) * 8 + 4);
+                v[u][0] = bev_tap<FT>(rsrc, o.x + lane_off);
+                v[u][1] = bev_tap<FT>(rsrc, o.y + lane_off);
+                v[u][2] = bev_tap<FT>(rsrc, o.z + lane_off);
+                v[u][3] = bev_tap<FT>(rsrc, o.w + lane_off);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc.x += tw[u][0] * v[u][0].x + tw[u][1] * v[u][1].x + tw[u][2] * v[u][2].x + tw[u][3] * v[u][3].x;
-                acc.y += tw[u][0] * v[u][0].y + tw[u][1] * v[u][1].y + tw[u][2] * v[u][2].y + tw[u][3] * v[u][3].y;
-                acc.z += tw[u][0] * v[u][0].z + tw[u][1] * v[u][1].z + tw[u][2] * v[u][2].z + tw[u][3] * v[u][3].z;
-                acc.w += tw[u][0] * v[u][0].w + tw[u][1] * v[u][1].w + tw[u][2] * v[u][2].w + tw[u][3] * v[u][3].w;
+            for (int u = 0; u < BEV_U; ++u) {
+                const float w4[4] = {tw[u].x, tw[u].y, tw[u].z, tw[u].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bev_f2 w2 = {w4[c], w4[c]};
+                    acc01 = __builtin_elementwise_fma((bev_f2){v[u][c].x, v[u][c].y}, w2, acc01);
+                    acc23 = __builtin_elementwise_fma((bev_f2){v[u][c].z, v[u][c].w}, w2, acc23);
+                }
             }
         }
     }
+    const rac_f4 acc = {acc01.x, acc01.y, acc23.x, acc23.y};
     // phase D: fixed-order sum of the four point subsets (deterministic, no atomics)
     *reinterpret_cast<rac_f4 *>(spart + (k * BEV_TS + ts) * 64 + c4 * 4) = acc;
     __syncthreads();
@@ -290,7 +351,7 @@ __global__ __launch_bounds__(256, 4) void bev_sampling_d64_kernel(const BevArgs 
             const rac_f4 pz = *reinterpret_cast<const rac_f4 *>(spart + (k * BEV_TS + u) * 64 + c4 * 4);
             o.x += pz.x; o.y += pz.y; o.z += pz.z; o.w += pz.w;
         }
-        *reinterpret_cast<rac_f4 *>(s.out + ((size_t)b * per_b + it) * 64 + c4 * 4) = o;
+        *reinterpret_cast<rac_f4 *>(s.out + ((size_t)b * per_b + (i0 + k)) * 64 + c4 * 4) = o;
     }
 }
 
@@ -306,12 +367,18 @@ static int bev_launch(int nstreams, const void *const *values, const float *cons
                   "rac_bev_sampling_fwd: bad sizes B=%d T=%d Q=%d heads=%d NP=%d D=%d H=%d W=%d", B, T, Q, heads, NP, D, H, W);
     RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_bev_sampling_fwd: dtype %d", dtype);
     const int P = NP * D;
-    const size_t lds = ((size_t)BEV_GI * T * P * 2 + (size_t)BEV_GI * (B > 1 ? T : 1) * P + (size_t)BEV_GI * T + (size_t)BEV_GI * P * 2 +
-                        (size_t)BEV_GI * BEV_MAX_DEPTH + (size_t)BEV_GI * BEV_TS * 64 + (size_t)BEV_GI * T * P * 8) * sizeof(float);
+    const int npp = (P + BEV_TS - 1) / BEV_TS;
+    const int list_len = (T * npp + BEV_U - 1) / BEV_U * BEV_U;
+    const size_t lds = ((size_t)BEV_GI * BEV_TS * list_len * 8 + (size_t)BEV_GI * BEV_TS * 64 + (size_t)BEV_GI * (B > 1 ? T : 1) * P +
+                        (size_t)BEV_GI * T + (size_t)BEV_GI * P * 2 + (size_t)BEV_GI * BEV_MAX_DEPTH + (size_t)BEV_GI * 2 + (size_t)T) * sizeof(float);
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_bev_sampling_fwd: T*P=%d too large for the LDS staging", T * P);
+    const size_t value_bytes = (size_t)B * T * H * W * heads * 64 * (dtype == RAC_F32 ? 4 : 2);
+    RAC_CHECK_ARG(value_bytes < (size_t)BEV_TAP_OUTSIDE, "rac_bev_sampling_fwd: value maps of %zu bytes (the tap offsets are 31-bit)", value_bytes);
     if (B == 0 || Q == 0)
         return 0;
     RAC_CHECK_ARG(box_table != nullptr, "rac_bev_sampling_fwd: box_table is null (run rac_box_prep_fwd first)");
+    RAC_CHECK_ARG((reinterpret_cast<uintptr_t>(box_table) & 15) == 0, "rac_bev_sampling_fwd: box_table must be 16-byte aligned");
+    RAC_CHECK_ARG(T <= 64, "rac_bev_sampling_fwd: T=%d frames (max 64: one lane per frame in the frame softmax)", T);
     RAC_CHECK_ARG(BEV_GI * P <= 128 && BEV_GI * D <= 64, "rac_bev_sampling_fwd: NP*D=%d (max %d) or D=%d (max %d) exceed the workgroup's staging roles", P, 128 / BEV_GI, D, 64 / BEV_GI);
     RAC_CHECK_ARG(values && offsets && ray_logits && scale_logits && queue_logits && outs && query_bbox && time_diff && pc_range && depth_base,
                   "rac_bev_sampling_fwd: null pointer");
@@ -332,6 +399,9 @@ static int bev_launch(int nstreams, const void *const *values, const float *cons
     a.B = B; a.T = T; a.Q = Q; a.heads = heads; a.NP = NP; a.D = D; a.P = P; a.H = H; a.W = W;
     a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale; a.ld_queue = ld_queue;
     a.blocks_per_b = (Q * heads + BEV_GI - 1) / BEV_GI;
+    a.value_bytes = (unsigned)value_bytes;
+    a.list_len = list_len;
+    a.list_holes = (P % BEV_TS != 0 || list_len != T * npp) ? 1 : 0;
     a.xcd_remap = 1;
     const dim3 grid(B * a.blocks_per_b, nstreams);
     hipStream_t st = (hipStream_t)stream;

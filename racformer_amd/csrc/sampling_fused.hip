@@ -14,9 +14,10 @@
 //
 // Workgroup = 4 waves = S4D_ROWS consecutive queries of one slot (b,t,g).  Phase 1: the first S4D_ROWS*P threads
 // compute one keypoint each (box decode, offset, yaw rotation, velocity warp, polar jitter,
-// projection into the N cameras of frame t, first valid view, softmax over levels) into LDS.
-// Phase 2: identical to msmv_fwd_c64_kernel -- 16-lane group per point, 16-byte loads, 16 taps in
-// flight, XCD-aware slot mapping, 1 KiB coalesced stores.
+// projection into the N cameras of frame t, first valid view, softmax over levels) and its tap table (per level: four
+// byte offsets + four weights) into LDS.
+// Phase 2: 16-lane group per point, 16-byte buffer loads (the descriptor's range check zero-fills taps outside the map),
+// 16 taps in flight, packed FMAs, XCD-aware slot mapping, 1 KiB coalesced stores.
 //
 // Index conventions reproduced from the reference: point p of a group = (num_point, depth) with
 // depth fastest (:394); slot s = (b*T+t)*G+g for points/features/outputs, but the scale weights of
@@ -25,7 +26,7 @@
 #include "rac_common.h"
 
 #ifndef S4D_ROWS
-#define S4D_ROWS 16 /* queries per workgroup: one prologue pass (up to 192 keypoints on 192 threads) serves 4 gather rounds */
+#define S4D_ROWS 8 /* queries per workgroup: one prologue pass (96 keypoints at P = 12) serves 2 gather rounds per wave; measured 4 / 8 / 12 / 16 / 32: 92.7 / 88.9 / 90.3 / 94 / 107 us */
 #endif
 #ifndef S4D_LB
 #define S4D_LB 4 /* levels per load batch (see the gather loop) */
@@ -40,6 +41,7 @@ struct S4dArgs {
     const void *feat[RAC_MAX_LEVELS];
     int H[RAC_MAX_LEVELS];
     int W[RAC_MAX_LEVELS];
+    unsigned feat_bytes[RAC_MAX_LEVELS];  // size of each level's buffer (the buffer descriptors' ranges)
     const float *qbox;       // [B,Q,10]
     const float *box;        // [B,Q,8] from rac_box_prep_fwd (cx,cy,cz,w,l,h,cos,sin)
     const float *off;        // [B,Q,G*P*3]
@@ -142,13 +144,26 @@ __device__ __forceinline__ void s4d_keypoint(const S4dArgs &a, const float *sl2i
         wl[l] = e[l] / sum;
 }
 
+#define S4D_TAP_OUTSIDE 0x80000000u   /* tap offset past the end of a level's buffer: the buffer load returns zeros */
+typedef float s4d_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int s4d_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int s4d_u4 __attribute__((ext_vector_type(4)));
+
+// Four channels of one tap through the level's buffer descriptor: its range check stands in for the branches of the
+// bilinear footprint (a tap outside the map carries the offset S4D_TAP_OUTSIDE and reads as zero).
 template <typename FT>
-__device__ __forceinline__ rac_f4 s4d_tap(const FT *base, int h, int w, int W, bool ok)
+__device__ __forceinline__ rac_f4 s4d_tap(__amdgpu_buffer_rsrc_t rsrc, unsigned off);
+template <>
+__device__ __forceinline__ rac_f4 s4d_tap<float>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
 {
-    rac_f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok)
-        v = rac_ld4(base + ((size_t)h * W + w) * 64);
-    return v;
+    return __builtin_bit_cast(rac_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ rac_f4 s4d_tap<unsigned short>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+{
+    const s4d_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);    // 4 x bf16
+    return (rac_f4){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                    __uint_as_float(r.y & 0xffff0000u)};
 }
 
 template <typename FT, int L>
@@ -169,91 +184,97 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
     const int nrows = min(a.rows, a.Q - q0);
     const int g = s % a.G, t = (s / a.G) % a.T, b = s / (a.G * a.T);
 
-    float *sloc = smem;                     // [rows][P][3]
-    float *sw = sloc + a.rows * P * 3;      // [rows][P][L]
-    float *sl2i = sw + a.rows * P * L;      // [N][16]
+    // tap table [L][rows*P][8]: per keypoint and level the 4 tap byte offsets into the level's buffer (S4D_TAP_OUTSIDE =
+    // outside the map) and the 4 bilinear weights with the level weight folded in -- computed once per keypoint by the
+    // prologue instead of by each of the 16 lanes that gather the point
+    float *stab = smem;
+    const int lstride = a.rows * P * 8;
+    float *sl2i = stab + L * lstride;       // [N][16]
     for (int i = tid; i < a.N * 16; i += 256)
         sl2i[i] = a.l2i[((size_t)b * a.T + t) * a.N * 16 + i];
     __syncthreads();
     for (int i = tid; i < nrows * P; i += 256) {
         const int r = i / P, p = i - r * P;
-        s4d_keypoint<L>(a, sl2i, b, t, g, q0 + r, p, sloc + i * 3, sw + i * L);
+        float loc3[3], wl[L];
+        s4d_keypoint<L>(a, sl2i, b, t, g, q0 + r, p, loc3, wl);
+        const float lu = loc3[0], lv = loc3[1];
+        const int view = (int)loc3[2] & 255;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int H = a.H[l], W = a.W[l];
+            const float h_im = lv * (float)(H - 1);
+            const float w_im = lu * (float)(W - 1);
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
+            const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+            const unsigned pix_bytes = (unsigned)(64 * sizeof(FT));
+            const unsigned mbase = (unsigned)(s * a.N + view) * (unsigned)(H * W) * pix_bytes;   // map (slot, camera) of the level
+            s4d_u4 off;
+            off.x = t_ok && l_ok ? mbase + (unsigned)(h_low * W + w_low) * pix_bytes : S4D_TAP_OUTSIDE;
+            off.y = t_ok && r_ok ? mbase + (unsigned)(h_low * W + w_high) * pix_bytes : S4D_TAP_OUTSIDE;
+            off.z = b_ok && l_ok ? mbase + (unsigned)(h_high * W + w_low) * pix_bytes : S4D_TAP_OUTSIDE;
+            off.w = b_ok && r_ok ? mbase + (unsigned)(h_high * W + w_high) * pix_bytes : S4D_TAP_OUTSIDE;
+            float *e = stab + l * lstride + i * 8;
+            *reinterpret_cast<s4d_u4 *>(e) = off;
+            *reinterpret_cast<rac_f4 *>(e + 4) = (rac_f4){hh * hw * wl[l], hh * lw * wl[l], lh * hw * wl[l], lh * lw * wl[l]};
+        }
         if (a.loc_out) {
             float *lo = a.loc_out + (((size_t)s * a.Q + q0 + r) * P + p) * 3;
-            lo[0] = sloc[i * 3];
-            lo[1] = sloc[i * 3 + 1];
+            lo[0] = lu;
+            lo[1] = lv;
             // loc_out reports the kernel's own first-valid-view choice (with view_in: beside the imposed one it sampled in)
-            lo[2] = (float)((int)sloc[i * 3 + 2] >> 8) / (float)max(a.N - 1, 1);
+            lo[2] = (float)((int)loc3[2] >> 8) / (float)max(a.N - 1, 1);
             float *wo = a.w_out + (((size_t)s * a.Q + q0 + r) * P + p) * L;
 #pragma unroll
             for (int l = 0; l < L; ++l)
-                wo[l] = sw[i * L + l];
+                wo[l] = wl[l];
         }
     }
     __syncthreads();
+    __amdgpu_buffer_rsrc_t rsrc[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+        rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.feat[l]), 0, a.feat_bytes[l], 0x00020000);
+    const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
     // wave w gathers rows w, w+4, ... of the workgroup's S4D_ROWS queries: the keypoint prologue above (one pass, its
-    // latency independent of the number of keypoints up to 256) is paid once per S4D_ROWS / 4 gather rounds
+    // latency independent of the number of keypoints up to 256) is paid once per S4D_ROWS / 4 gather rounds.  Per tap:
+    // one add for the lane's channel offset, one buffer load, two packed FMAs.
     for (int row = wave; row < nrows; row += 4) {
-    const int q = q0 + row;
-    const size_t out_row = ((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * (size_t)P * 64;
-
-    for (int p0 = 0; p0 < P; p0 += 4) {
-        const int p = p0 + sub;
-        const bool act = p < P;
-        const int pp = act ? p : P - 1;
-        const float *lp = sloc + (row * P + pp) * 3;
-        const float *wp = sw + (row * P + pp) * L;
-        const float lu = lp[0], lv = lp[1];
-        const int view = (int)lp[2] & 255;
-
-        rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
-        // levels are processed LB at a time: LB*4 tap loads in flight per lane.  LB trades loads in
-        // flight per wave against registers (occupancy): S4D_LB=2 -> ~80 VGPR, 6 waves/SIMD.
+        const int q = q0 + row;
+        const size_t out_row = ((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * (size_t)P * 64;
+        for (int p0 = 0; p0 < P; p0 += 4) {
+            const int p = p0 + sub;
+            const bool act = p < P;
+            const float *e = stab + (row * P + (act ? p : P - 1)) * 8;
+            rac_f4 v[L][4], tw[L];
 #pragma unroll
-        for (int l0 = 0; l0 < L; l0 += S4D_LB) {
-            rac_f4 v[S4D_LB][4];
-            float tw[S4D_LB][4];
+            for (int l = 0; l < L; ++l) {
+                const s4d_u4 o = *reinterpret_cast<const s4d_u4 *>(e + l * lstride);
+                tw[l] = *reinterpret_cast<const rac_f4 *>(e + l * lstride + 4);
+                v[l][0] = s4d_tap<FT>(rsrc[l], o.x + lane_off);
+                v[l][1] = s4d_tap<FT>(rsrc[l], o.y + lane_off);
+                v[l][2] = s4d_tap<FT>(rsrc[l], o.z + lane_off);
+                v[l][3] = s4d_tap<FT>(rsrc[l], o.w + lane_off);
+            }
+            s4d_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < S4D_LB; ++k) {
-                const int l = l0 + k;
-                if (l < L) {
-                    const int H = a.H[l], W = a.W[l];
-                    const float h_im = lv * (float)(H - 1);
-                    const float w_im = lu * (float)(W - 1);
-                    const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                    const float hf = floorf(h_im), wf = floorf(w_im);
-                    const int h_low = (int)hf, w_low = (int)wf;
-                    const int h_high = h_low + 1, w_high = w_low + 1;
-                    const float lh = h_im - hf, lw = w_im - wf;
-                    const float hh = 1.f - lh, hw = 1.f - lw;
-                    const FT *base = (const FT *)a.feat[l] + ((size_t)s * a.N + view) * H * W * 64 + c4 * 4;
-                    const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
-                    const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-                    v[k][0] = s4d_tap(base, h_low, w_low, W, t_ok && l_ok);
-                    v[k][1] = s4d_tap(base, h_low, w_high, W, t_ok && r_ok);
-                    v[k][2] = s4d_tap(base, h_high, w_low, W, b_ok && l_ok);
-                    v[k][3] = s4d_tap(base, h_high, w_high, W, b_ok && r_ok);
-                    tw[k][0] = hh * hw;
-                    tw[k][1] = hh * lw;
-                    tw[k][2] = lh * hw;
-                    tw[k][3] = lh * lw;
+            for (int l = 0; l < L; ++l) {
+                const float w4[4] = {tw[l].x, tw[l].y, tw[l].z, tw[l].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const s4d_f2 w2 = {w4[c], w4[c]};
+                    acc01 = __builtin_elementwise_fma((s4d_f2){v[l][c].x, v[l][c].y}, w2, acc01);
+                    acc23 = __builtin_elementwise_fma((s4d_f2){v[l][c].z, v[l][c].w}, w2, acc23);
                 }
             }
-#pragma unroll
-            for (int k = 0; k < S4D_LB; ++k) {
-                const int l = l0 + k;
-                if (l < L) {
-                    const float wl = wp[l];
-                    acc.x += (tw[k][0] * v[k][0].x + tw[k][1] * v[k][1].x + tw[k][2] * v[k][2].x + tw[k][3] * v[k][3].x) * wl;
-                    acc.y += (tw[k][0] * v[k][0].y + tw[k][1] * v[k][1].y + tw[k][2] * v[k][2].y + tw[k][3] * v[k][3].y) * wl;
-                    acc.z += (tw[k][0] * v[k][0].z + tw[k][1] * v[k][1].z + tw[k][2] * v[k][2].z + tw[k][3] * v[k][3].z) * wl;
-                    acc.w += (tw[k][0] * v[k][0].w + tw[k][1] * v[k][1].w + tw[k][2] * v[k][2].w + tw[k][3] * v[k][3].w) * wl;
-                }
-            }
+            if (act)
+                *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = (rac_f4){acc01.x, acc01.y, acc23.x, acc23.y};
         }
-        if (act)
-            *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = acc;
-    }
     }
 }
 
@@ -286,12 +307,16 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
     for (int l = 0; l < RAC_MAX_LEVELS; ++l) {
         a.feat[l] = nullptr;
         a.H[l] = a.W[l] = 1;
+        a.feat_bytes[l] = 0;
     }
     for (int l = 0; l < L; ++l) {
         RAC_CHECK_ARG(feats[l] != nullptr && hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "rac_sampling4d_fwd: level %d", l);
         a.feat[l] = feats[l];
         a.H[l] = hw[2 * l];
         a.W[l] = hw[2 * l + 1];
+        const size_t bytes = (size_t)B * T * G * N * a.H[l] * a.W[l] * 64 * (dtype == RAC_F32 ? 4 : 2);
+        RAC_CHECK_ARG(bytes < (size_t)S4D_TAP_OUTSIDE, "rac_sampling4d_fwd: level %d holds %zu bytes (the tap offsets are 31-bit)", l, bytes);
+        a.feat_bytes[l] = (unsigned)bytes;
     }
     a.qbox = query_bbox; a.box = box_table; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
     a.time_diff = time_diff; a.l2i = lidar2img; a.out = out; a.loc_out = loc_out; a.w_out = w_out; a.view_in = view_in;
@@ -306,7 +331,8 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
     a.blocks_per_slot = (Q + a.rows - 1) / a.rows;
     const int S = B * T * G;
     const int nb = 8 * ((S + 7) / 8) * a.blocks_per_slot;
-    const size_t lds = ((size_t)a.rows * P * (3 + L) + (size_t)N * 16) * sizeof(float);
+    const size_t lds = ((size_t)a.rows * P * 8 * L + (size_t)N * 16) * sizeof(float);
+    RAC_CHECK_ARG(lds <= 64 * 1024, "rac_sampling4d_fwd: P=%d x L=%d too large for the LDS tap table", P, L);
     hipStream_t st = (hipStream_t)stream;
 #define S4D_LAUNCH(FT, LL) hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL>), dim3(nb), dim3(256), lds, st, a)
     if (dtype == RAC_F32) {

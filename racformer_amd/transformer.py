@@ -959,6 +959,13 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         at = self.self_attn
         sasa_w = self._cached("sasa", [at.attention.attn.in_proj_weight, at.gen_tau.weight, at.attention.attn.in_proj_bias,
                                        at.gen_tau.bias], at.wide_in_proj)
+        # K-slices of the two Linears with K > 256 (fusion: 768, FFN w2: 512): each slice runs as its own 256-deep GEMM in
+        # the same launch, the consumer's prologue sums the partial outputs
+        E_ = self.embed_dims
+        w2_ = self.ffn.layers[1]
+        kslices = self._cached("kslices", [self.fusion.weight, w2_.weight], lambda: (
+            [self.fusion.weight[:, i * E_:(i + 1) * E_].contiguous() for i in range(self.fusion.weight.shape[1] // E_)],
+            [w2_.weight[:, i * E_:(i + 1) * E_].contiguous() for i in range(w2_.weight.shape[1] // E_)]))
         packs = {}
         if self.split_gemm and radar_value.is_cuda and self.fused:
             # |norm1 output| <= sqrt(E) * max|gamma| + max|beta| bounds the generator's A operand
@@ -968,7 +975,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         out_proj_split = None if packs else self._cached("out_proj_split", [mix.out_proj.weight], mix.split_out_proj)
         return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
                     wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=out_proj_split, split_packs=packs,
-                    sasa_w=sasa_w, bev_owt=bev_owt, bev_ob=bev_ob, c0r0_w=c0r0_w, c0r0_b=c0r0_b)
+                    sasa_w=sasa_w, bev_owt=bev_owt, bev_ob=bev_ob, c0r0_w=c0r0_w, c0r0_b=c0r0_b,
+                    fusion_k=kslices[0], ffn2_k=kslices[1])
 
     def forward_fused(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None):
         """The layer as hand-written HIP kernels plus the three big library GEMMs of the mixing: every small Linear is
@@ -1042,20 +1050,23 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # thirds are normalised in the GEMM's prologue
         x2 = add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0],
                     a_scale=p_scale)
-        f_raw = new(n, E)
-        rowgemm_launch([row_gemm([row_seg(x2),
-                                  row_seg(proj[0], residual=x1, norm=self.norm_radar_bev),
-                                  row_seg(proj[1], residual=x1, norm=self.norm_lss_bev)],
-                                 self.fusion.weight, self.fusion.bias, f_raw)], n)
-        # FFN: f = norm_fusion(f_raw); h1 = relu(W1 f); ffn_lin = W2 h1; x3 = norm3(f + ffn_lin)
-        f, h1, ffn_lin = new(n, E), new(n, 2 * E), new(n, E)
+        # The fusion Linear (K = 768) as three 256-deep GEMMs side by side in one launch (3 x 228 workgroups, each with a
+        # third of the prologue and of the k-loop); its consumer sums the three partial outputs in its prologue.
+        fk, f2k = prepared["fusion_k"], prepared["ffn2_k"]
+        if len(fk) != 3 or len(f2k) != 2:
+            raise RuntimeError("forward_fused: fusion must take 3 * embed_dims, feedforward_channels must be 2 * embed_dims")
+        f_parts = new(3, n, E)
+        rowgemm_launch([row_gemm([row_seg(x2)], fk[0], self.fusion.bias, f_parts[0]),
+                        row_gemm([row_seg(proj[0], residual=x1, norm=self.norm_radar_bev)], fk[1], None, f_parts[1]),
+                        row_gemm([row_seg(proj[1], residual=x1, norm=self.norm_lss_bev)], fk[2], None, f_parts[2])], n)
+        # FFN: f = norm_fusion(f_raw); h1 = relu(W1 f); ffn_lin = W2 h1 (two K-slices); x3 = norm3(f + ffn_lin)
+        f, h1, ffn_parts = new(n, E), new(n, 2 * E), new(2, n, E)
         w1, w2 = self.ffn.layers[0][0], self.ffn.layers[1]
-        if w1.weight.shape[0] != 2 * E:
-            raise RuntimeError("forward_fused: feedforward_channels must be 2 * embed_dims")
-        rowgemm_launch([row_gemm([row_seg(f_raw, norm=self.norm_fusion, x_out=f)], w1.weight, w1.bias, h1, relu_from=0)], n)
-        rowgemm_launch([row_gemm([row_seg(h1[:, :E]), row_seg(h1[:, E:])], w2.weight, w2.bias, ffn_lin)], n)
+        rowgemm_launch([row_gemm([row_seg(f_parts, num_partials=3, norm=self.norm_fusion, x_out=f)], w1.weight, w1.bias, h1, relu_from=0)], n)
+        rowgemm_launch([row_gemm([row_seg(h1[:, :E])], f2k[0], w2.bias, ffn_parts[0]),
+                        row_gemm([row_seg(h1[:, E:])], f2k[1], None, ffn_parts[1])], n)
         x3, c0r0 = new(B, Q, E), new(n, 2 * E)
-        rowgemm_launch([row_gemm([row_seg(ffn_lin, residual=f, norm=self.norm3, x_out=x3)], prepared["c0r0_w"],
+        rowgemm_launch([row_gemm([row_seg(ffn_parts, num_partials=2, residual=f, norm=self.norm3, x_out=x3)], prepared["c0r0_w"],
                                  prepared["c0r0_b"], c0r0, relu_from=E)], n)       # (ReLU only on the reg half)
         # cls / reg branches side by side
         cb, rg = self.cls_branch, self.reg_branch
@@ -1074,7 +1085,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             mixed = x1 + p_scale * partials.sum(0).view_as(x1) + self.mixing.out_proj.bias
             stages.update(position_encoder=x - query_feat, self_attn=x + attn.view_as(x),
                           sampling_radar_bev=proj[0].view_as(x1) + x1, sampling_lss_bev=proj[1].view_as(x1) + x1,
-                          sampling=sampled_feat, mixing=mixed, ffn=(f + ffn_lin).view_as(x1))
+                          sampling=sampled_feat, mixing=mixed, ffn=(f + ffn_parts.sum(0)).view_as(x1))
         self.last_bbox_xy = bbox_xy
         return x3, cls_score, bbox_pred
 

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define RAC_ABI_VERSION 2
+#define RAC_ABI_VERSION 3
 #define RAC_MAX_LEVELS 8
 #define RAC_MAX_POINTS 128 /* same limit as the reference, msmv_sampling_forward.cu:21 */
 
@@ -171,6 +171,12 @@ int rac_bev_sampling_multi_fwd(int nstreams, const void *const *values, const fl
 int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, const float *box_table, float *out,
                  int ld_qkv, int ld_tau, int B, int Q, int heads, int dim, const float *pc_range, void *stream);
 
+/* Layouts of the f16 hi / lo activation images that rac_add_ln_fwd and rac_rowgemm_fwd can emit beside their fp32 rows */
+enum {
+    RAC_SPLIT_KCAT = 0,    /* rows [hi dim | hi dim | lo dim | pad]: A operand of a K-concatenated library GEMM */
+    RAC_SPLIT_LINES = 1    /* rows [dim/32 lines][hi 32 | lo 32]: X image of rac_generator_fwd (dim = 256: 1 KB per row) */
+};
+
 /* Row-wise  out = [relu]( LayerNorm( a_scale * sum_{s<num_partials} a[s] + residual + bias ) * gamma + beta ) [+ post_residual].
  * Replaces the add / bias / split-K reduce + nn.LayerNorm (+ ReLU) (+ add) launch groups of the decoder layer
  * (models/racformer_transformer.py:170-177, 199-205, 243-258).  a: device f32, row r of partial s at
@@ -179,12 +185,13 @@ int rac_sasa_fwd(const float *qkv, const float *tau, const float *query_bbox, co
  * split_out (optional, NULL to skip): device f16 [rows][3*dim + split_pad] = [hi | hi | lo | pad] with
  * out*split_scale = hi + lo -- the K-concatenated A operand of a 3-product split GEMM (hi*Whi + hi*Wlo + lo*Whi,
  * fp32 accumulate) on the f16 matrix cores, for the Linear layers that consume this row (split_scale: a power of
- * two).  split_pad (0 or a multiple of 4) extra columns: the first two hold split_scale (the activation 1.0, which
+ * two).  split_layout = RAC_SPLIT_LINES instead writes the line image [rows][dim/32][hi 32 | lo 32] (split_pad 0).
+ * split_pad (0 or a multiple of 4) extra columns: the first two hold split_scale (the activation 1.0, which
  * meets [bias_hi | bias_lo] in the weight image, so the GEMM adds the bias itself), the others 0. */
 int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, float a_scale, const float *residual,
                    const float *bias, const float *gamma, const float *beta, const float *post_residual,
                    float *out, int ld_out, int rows, int dim, float eps, int relu, void *split_out,
-                   float split_scale, int split_pad, void *stream);
+                   float split_scale, int split_pad, int split_layout, void *stream);
 
 /* Position-encoder head  out = relu(LayerNorm(W x + b))  for the 3-wide box input
  * (models/racformer_transformer.py:170-173); x row r at x + r*ld_x (3 values), weight [256,3], out [rows,256]. */
@@ -244,10 +251,12 @@ int rac_outproj_fwd(const void *z_image, const void *w_image, float *partials, i
 
 /* AdaptiveMixing.parameter_generator (nn.Linear(256 -> groups*(64*64 + 128*in_points)), models/racformer_transformer.py:565,589)
  * on the same hand-written kernel:  out[m][n] = alpha * sum_k X[m][k] * W[n][k] + bias[n]   (alpha undoes the two powers of two
- * of the images).  One workgroup per 256 features walks all rows: the weights cross the fabric once.
+ * of the images).  One workgroup per 256 features walks all rows: the weights cross the fabric once.  Also the eleven Linears
+ * of the three sampling modules (256 -> 2189, models/racformer_transformer.py:361-366, 490-500): for narrow outputs the rows
+ * are cut into chunks so that feature blocks x chunks covers the CUs.
  *   x_image : device f16 line image [M][K/32][hi 32 | lo 32]   (rac_rowgemm_fwd's split_out, split_layout = RAC_SPLIT_LINES)
  *   w_image : device f16 line image [N][K/32][hi 32 | lo 32]   (rac_gemm_split_pack_fwd);  bias device f32 [N] or NULL
- *   out     : device f32, row m at out + m*ld_out;  K % 32 == 0, N % 4 == 0, ld_out % 4 == 0 */
+ *   out     : device f32, row m at out + m*ld_out;  K % 32 == 0, ld_out % 4 == 0, N % 4 == 0 unless K == 256 */
 int rac_generator_fwd(const void *x_image, const void *w_image, const float *bias, float alpha, float *out, int64_t ld_out, int M,
                       int N, int K, void *stream);
 
@@ -292,10 +301,6 @@ int rac_upsample2x_fwd(const float *src, float *dst, int64_t planes, int h, int 
  * the finished segment; split_out (optional) its f16 [hi | hi | lo | pad] image (layout of rac_add_ln_fwd's split_out).
  * Up to RAC_ROWGEMM_MAX_BATCH independent GEMMs over the same `rows` share the launch (descs: HOST array). */
 #define RAC_ROWGEMM_MAX_BATCH 3
-enum {
-    RAC_SPLIT_KCAT = 0,    /* split_out rows [hi 256 | hi 256 | lo 256 | pad]: A operand of a K-concatenated library GEMM */
-    RAC_SPLIT_LINES = 1    /* split_out rows [8 lines][hi 32 | lo 32] (1 KB): X image of rac_generator_fwd */
-};
 typedef struct {
     const float *a;
     int64_t partial_stride;

@@ -31,7 +31,7 @@ SIGNATURES = {
     "rac_msda_bwd": (_i, [_vp] * 9 + [_i] * 7 + [_vp]),
     "rac_bev_pool_v2_fwd": (_i, [_vp] * 8 + [_i, _i, _vp]),
     "rac_bev_pool_v2_bwd": (_i, [_vp] * 10 + [_i, _i, _vp]),
-    "rac_add_ln_fwd": (_i, [_vp, _i, ctypes.c_int64, _i, _f] + [_vp] * 6 + [_i, _i, _i, _f, _i, _vp, _f, _i, _vp]),
+    "rac_add_ln_fwd": (_i, [_vp, _i, ctypes.c_int64, _i, _f] + [_vp] * 6 + [_i, _i, _i, _f, _i, _vp, _f, _i, _i, _vp]),
     "rac_pe_head_fwd": (_i, [_vp, _i] + [_vp] * 5 + [_i, _i, _f, _vp]),
     "rac_layer_boundary_fwd": (_i, [_vp] * 12 + [_i] * 4 + [_f, _f, _vp]),
     "rac_refine_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_f, _vp]),

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                                      const float *__restrict__ post, float *__restrict__ out, int ld_out,
                                                      int rows, int dim, float eps, int relu,
-                                                     _Float16 *__restrict__ split_out, float split_scale, int split_pad)
+                                                     _Float16 *__restrict__ split_out, float split_scale, int split_pad, int split_lines)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -37,9 +37,20 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
         x[k] = (rac_f4){0.f, 0.f, 0.f, 0.f};
         if (c < nv) {
             rac_f4 v = rac_ld4(a + (size_t)row * ld_a + c * 4);
-            for (int s = 1; s < S; ++s) {
-                const rac_f4 w = rac_ld4(a + (size_t)s * pstride + (size_t)row * ld_a + c * 4);
-                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            // split-K partials eight at a time: eight independent loads in flight per lane instead of one dependent load
+            // per partial (32 partials of the mixing's out_proj: 4 memory latencies, not 31); the sum keeps its order
+            for (int s0 = 1; s0 < S; s0 += 8) {
+                rac_f4 w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    w[j] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+                    if (s0 + j < S)
+                        w[j] = rac_ld4(a + (size_t)(s0 + j) * pstride + (size_t)row * ld_a + c * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v.x += w[j].x; v.y += w[j].y; v.z += w[j].z; v.w += w[j].w;
+                }
             }
             v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
             if (bias) {
@@ -89,6 +100,13 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
                 rac_split_f16(y.y * split_scale, hi.y, lo.y);
                 rac_split_f16(y.z * split_scale, hi.z, lo.z);
                 rac_split_f16(y.w * split_scale, hi.w, lo.w);
+                if (split_lines) {
+                    // line image [dim/32 lines][hi 32 | lo 32]: the X operand of rac_generator_fwd (a lane's 4 columns sit in one line)
+                    _Float16 *dl = split_out + (size_t)row * (2 * dim) + (c >> 3) * 64 + (c & 7) * 4;
+                    *reinterpret_cast<rac_h4 *>(dl) = hi;
+                    *reinterpret_cast<rac_h4 *>(dl + 32) = lo;
+                    continue;
+                }
                 _Float16 *dst = split_out + (size_t)row * (3 * dim + split_pad) + c * 4;
                 *reinterpret_cast<rac_h4 *>(dst) = hi;
                 *reinterpret_cast<rac_h4 *>(dst + dim) = hi;
@@ -134,8 +152,10 @@ __global__ __launch_bounds__(256) void pe_head_kernel(const float *__restrict__ 
 extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int ld_a, float a_scale, const float *residual,
                               const float *bias, const float *gamma, const float *beta, const float *post_residual,
                               float *out, int ld_out, int rows, int dim, float eps, int relu, void *split_out,
-                              float split_scale, int split_pad, void *stream)
+                              float split_scale, int split_pad, int split_layout, void *stream)
 {
+    RAC_CHECK_ARG(split_layout == RAC_SPLIT_KCAT || (split_layout == RAC_SPLIT_LINES && dim % 32 == 0 && split_pad == 0),
+                  "rac_add_ln_fwd: split_layout=%d (RAC_SPLIT_LINES needs dim %% 32 == 0 and split_pad == 0)", split_layout);
     RAC_CHECK_ARG(rows >= 0 && dim >= 4 && dim % 4 == 0 && dim <= 256 * ALN_MAX_V, "rac_add_ln_fwd: dim=%d (multiple of 4, <= %d)", dim, 256 * ALN_MAX_V);
     RAC_CHECK_ARG(num_partials >= 1, "rac_add_ln_fwd: num_partials=%d", num_partials);
     RAC_CHECK_ARG(!split_out || split_pad == 0 || (split_pad >= 2 && split_pad % 4 == 0), "rac_add_ln_fwd: split_pad=%d (0, or a multiple of 4)", split_pad);
@@ -145,7 +165,7 @@ extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_
     RAC_CHECK_ARG(a && gamma && beta && out, "rac_add_ln_fwd: null pointer");
     hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, num_partials,
                        (long)partial_stride, ld_a, a_scale, residual, bias, gamma, beta, post_residual, out, ld_out, rows, dim, eps, relu,
-                       reinterpret_cast<_Float16 *>(split_out), split_scale, split_pad);
+                       reinterpret_cast<_Float16 *>(split_out), split_scale, split_pad, split_layout == RAC_SPLIT_LINES ? 1 : 0);
     return rac_launch_status("rac_add_ln_fwd");
 }
 

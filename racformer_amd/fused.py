@@ -257,12 +257,14 @@ def layer_boundary_fused(proposal, delta, time_diff_safe, num_ray, pc_range, pe_
     return pred, xy, table, h
 
 
-def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=None, out=None, split=False, a_scale=1.0):
+def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=None, out=None, split=False, a_scale=1.0,
+           split_lines=False, split_out=None):
     """[relu](LayerNorm(a_scale * sum_s a[s] + residual + bias)) [+ post] with ``norm`` an nn.LayerNorm; a is [..., dim]
     (unit inner stride; rows may be a column slice of a wider tensor) or [S, ..., dim] with num_partials=S.
     ``out``: optional destination (may itself be a column slice).  One launch.
     ``split=True``: also returns the f16 [rows, 3*dim + SPLIT_BIAS_PAD] = [hi | hi | lo | 1 1 0..] image of
-    ``out * SPLIT_ACT_SCALE`` (A operand of a split GEMM, see ``split_weight_f16``)."""
+    ``out * SPLIT_ACT_SCALE`` (A operand of a split GEMM, see ``split_weight_f16``); with ``split_lines`` the image is the
+    line image [rows, dim/32 * 64] = [hi 32 | lo 32] per 32 columns that ``generator_fused`` reads."""
     _lib.require_gpu(norm.weight, what="add_ln")
     dim = a.shape[-1]
     if num_partials > 1:
@@ -289,13 +291,18 @@ def add_ln(a, norm, residual=None, bias=None, relu=False, num_partials=1, post=N
         if out.stride(-1) != 1 or out.shape[-1] != dim:
             raise RuntimeError("add_ln: out must have unit inner stride and the normalised width")
         ld_out = out.stride(-2)
-    split_out = torch.empty(rows, 3 * dim + SPLIT_BIAS_PAD, device=a.device, dtype=torch.float16) if split else None
+    if split:
+        width = 2 * dim if split_lines else 3 * dim + SPLIT_BIAS_PAD
+        if split_out is None:
+            split_out = torch.empty(rows, width, device=a.device, dtype=torch.float16)
+        elif split_out.dtype != torch.float16 or not split_out.is_contiguous() or tuple(split_out.shape) != (rows, width):
+            raise RuntimeError(f"add_ln: split_out must be a contiguous f16 [{rows}, {width}] tensor")
     rc = _lib.lib().rac_add_ln_fwd(_lib.ptr(a), num_partials, rows * dim, ld_a, float(a_scale),
                                    _lib.ptr(residual) if residual is not None else None,
                                    _lib.ptr(bias) if bias is not None else None, _lib.ptr(norm.weight), _lib.ptr(norm.bias),
                                    _lib.ptr(post) if post is not None else None, _lib.ptr(out), ld_out, rows, dim,
                                    float(norm.eps), int(relu), _lib.ptr(split_out) if split else None,
-                                   SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, _lib.stream_ptr())
+                                   SPLIT_ACT_SCALE, 0 if split_lines else SPLIT_BIAS_PAD, 1 if split_lines else 0, _lib.stream_ptr())
     _lib.check(rc, "rac_add_ln_fwd")
     return (out, split_out) if split else out
 
@@ -583,20 +590,21 @@ def pack_gemm_split_weight(weight):
     return img, 2.0 ** (-s) / SPLIT_ACT_SCALE
 
 
-def generator_fused(x_image, w_image, bias, alpha):
-    """x_image f16 [M, K/32 * 64] (row_seg(split_lines=True)), w_image f16 [N, K/32, 64] -> fp32 [M, N] = alpha * X @ W^T + bias
-    (rac_generator_fwd), one launch."""
+def generator_fused(x_image, w_image, bias, alpha, timer_name="mixing_generator_gemm", ld_out=None):
+    """x_image f16 [M, K/32 * 64] (row_seg(split_lines=True) / add_ln(split_lines=True)), w_image f16 [N, K/32, 64] -> fp32 [M, N] =
+    alpha * X @ W^T + bias (rac_generator_fwd), one launch."""
     _lib.require_gpu(x_image, w_image, what="generator_fused")
     M = x_image.shape[0]
     N, lines, _ = w_image.shape
     if x_image.dtype != torch.float16 or w_image.dtype != torch.float16 or x_image.numel() != M * lines * 64 or w_image.shape[2] != 64:
         raise RuntimeError("generator_fused: operand images do not match")
-    out = torch.empty(M, N, device=x_image.device, dtype=torch.float32)
-    ev = _lib.timer.record("mixing_generator_gemm") if _lib.timer is not None else None
+    ld_out = N if ld_out is None else int(ld_out)     # (row stride: a multiple of 4, >= N; the result has ld_out columns)
+    out = torch.empty(M, ld_out, device=x_image.device, dtype=torch.float32)
+    ev = _lib.timer.record(timer_name) if _lib.timer is not None and timer_name else None
     if ev:
         ev[0].record()
     rc = _lib.lib().rac_generator_fwd(_lib.ptr(x_image), _lib.ptr(w_image), _lib.ptr(bias) if bias is not None else None, float(alpha),
-                                      _lib.ptr(out), N, M, N, lines * 32, _lib.stream_ptr())
+                                      _lib.ptr(out), ld_out, M, N, lines * 32, _lib.stream_ptr())
     if ev:
         ev[1].record()
     _lib.check(rc, "rac_generator_fwd")

@@ -972,9 +972,11 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             packs = self._cached("split_packs", [mix.parameter_generator.weight, mix.parameter_generator.bias,
                                                  mix.out_proj.weight, self.norm1.weight, self.norm1.bias], lambda: mix.split_packs(
                 float(self.norm1.weight.abs().max()) * math.sqrt(self.embed_dims) + float(self.norm1.bias.abs().max())))
+        # the wide Linear on the same split-precision kernel as the generator (it reads the same f16 image of norm1's output)
+        wide_img = self._cached("wide_img", [w], lambda: pack_gemm_split_weight(w)) if packs and self.own_generator else (None, None)
         out_proj_split = None if packs else self._cached("out_proj_split", [mix.out_proj.weight], mix.split_out_proj)
         return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
-                    wide_w=w, wide_b=b, wide_widths=widths, out_proj_split=out_proj_split, split_packs=packs,
+                    wide_w=w, wide_b=b, wide_widths=widths, wide_img=wide_img, out_proj_split=out_proj_split, split_packs=packs,
                     sasa_w=sasa_w, bev_owt=bev_owt, bev_ob=bev_ob, c0r0_w=c0r0_w, c0r0_b=c0r0_b,
                     fusion_k=kslices[0], ffn2_k=kslices[1])
 
@@ -1014,9 +1016,18 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         x1 = new(B, Q, E)
         own_gen = bool(packs) and self.own_generator
         x1_split = torch.empty(n, 2 * E if own_gen else 3 * E + SPLIT_BIAS_PAD, device=dev, dtype=torch.float16) if packs else None
-        wide = new(B, Q, prepared["wide_w"].shape[0])
-        rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split, split_lines=own_gen)],
-                                 prepared["wide_w"], prepared["wide_b"], wide)], n)
+        wide_n = prepared["wide_w"].shape[0]
+        wimg, walpha = prepared.get("wide_img", (None, None))
+        if own_gen and wimg is not None:
+            # norm1 as its own row-wise launch (fp32 rows + f16 line image), then the 2189 outputs on the weights-stationary
+            # split-precision kernel: 6 + 7 us against 30 for the fp32-MFMA row GEMM, whose 57 row tiles each re-read all weights
+            add_ln(attn.view(B, Q, E), self.norm1, residual=x, out=x1, split=True, split_lines=True, split_out=x1_split)
+            wide = generator_fused(x1_split, wimg, prepared["wide_b"], walpha, timer_name=None, ld_out=(wide_n + 3) // 4 * 4)
+            wide = wide.view(B, Q, -1)[..., :wide_n]
+        else:
+            wide = new(B, Q, wide_n)
+            rowgemm_launch([row_gemm([row_seg(attn, residual=x, norm=self.norm1, x_out=x1, split_out=x1_split, split_lines=own_gen)],
+                                     prepared["wide_w"], prepared["wide_b"], wide)], n)
         lin = wide.split(prepared["wide_widths"], dim=-1)
         rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
         r_off, r_ray, r_sc, r_qu = lin[3:7]

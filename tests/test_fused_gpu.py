@@ -247,11 +247,13 @@ def test_outproj_kernel_vs_float64(M, N, K, S):
         assert err <= 3e-6 * float(want.abs().max()) + 1e-6 * float((zv.abs().max() * wv.abs().max())) * ks ** 0.5, (s_, err)
 
 
-@pytest.mark.parametrize("M,N,K", [(900, 4096, 256), (900, 65536, 256), (37, 520, 64), (129, 256, 32), (1, 4, 96)])
+@pytest.mark.parametrize("M,N,K", [(900, 4096, 256), (900, 65536, 256), (37, 520, 64), (129, 256, 32), (1, 4, 96),
+                                   (900, 2189, 256), (70, 777, 256), (33, 30, 256)])
 def test_generator_kernel_vs_float64(M, N, K):
     """rac_generator_fwd (the same kernel, persistent over the row tiles of a feature tile, affine epilogue) against float64:
-    ragged rows (tiles of unequal height, skipped MFMA tiles), ragged features (N % 256 != 0), bias, alpha; and the X line
-    image written by rac_rowgemm_fwd's prologue for K = 256."""
+    ragged rows (tiles of unequal height, skipped MFMA tiles), ragged features (N % 256 != 0, N % 4 != 0 with a padded row
+    stride: the 2189 outputs of the sampling Linears, rows cut into chunks), bias, alpha; and the X line image written by
+    rac_rowgemm_fwd's prologue (K = 256, N % 4 == 0) or rac_add_ln_fwd (N % 4 != 0)."""
     from racformer_amd.fused import SPLIT_ACT_SCALE, generator_fused, pack_gemm_split_weight, row_gemm, row_seg, rowgemm_launch
     g = torch.Generator().manual_seed(M + N)
     lin = torch.nn.Linear(K, N)
@@ -265,14 +267,23 @@ def test_generator_kernel_vs_float64(M, N, K):
         # the image as the decoder produces it: finished rows of a rowgemm prologue (here: plain copy of x), written beside a
         # throw-away 16-column GEMM
         img = torch.empty(M, 512, device=DEV, dtype=torch.float16)
-        dummy_w, dummy_out = torch.zeros(16, 256, device=DEV), torch.empty(M, 16, device=DEV)
-        rowgemm_launch([row_gemm([row_seg(x, split_out=img, split_lines=True)], dummy_w, None, dummy_out)], M)
+        if N % 4 == 0:
+            dummy_w, dummy_out = torch.zeros(16, 256, device=DEV), torch.empty(M, 16, device=DEV)
+            rowgemm_launch([row_gemm([row_seg(x, split_out=img, split_lines=True)], dummy_w, None, dummy_out)], M)
+        else:
+            # the image as rac_add_ln_fwd writes it: x := LN(a) with the layer's own affine, the GEMM then runs on that x
+            from racformer_amd.fused import add_ln
+            ln = torch.nn.LayerNorm(256).to(DEV)
+            with torch.no_grad():
+                ln.weight.copy_(torch.rand(256, generator=g) + 0.5)
+                ln.bias.copy_(torch.randn(256, generator=g) * 0.1)
+            x, _ = add_ln(x, ln, split=True, split_lines=True, split_out=img)
     else:
         xs = x * SPLIT_ACT_SCALE
         hi = xs.to(torch.float16)
         lo = (xs - hi.float()).to(torch.float16)
         img = torch.stack([hi.view(M, K // 32, 32), lo.view(M, K // 32, 32)], dim=2).reshape(M, K // 32 * 64).contiguous()
-    got = generator_fused(img, w_img, lin.bias, alpha)
+    got = generator_fused(img, w_img, lin.bias, alpha, ld_out=(N + 3) // 4 * 4)[:, :N]
     want = x.double() @ lin.weight.double().t() + lin.bias.double()
     e_split = (got.double() - want).abs().max().item()
     e_fp32 = (lin(x).double() - want).abs().max().item()

@@ -78,18 +78,24 @@ def test_c_abi_argument_errors_without_gpu():
     p8 = ctypes.c_void_p(8)
     pc = (ctypes.c_float * 6)(*syn.PC_RANGE)
     db = (ctypes.c_float * 3)(-0.1, 0.0, 0.1)
-    rc = lib.rac_sampling4d_fwd(one, hw, 4, p8, p8, p8, p8, p8, p8, p8, p8, None, None, 144, 3, 1536, 1, 8, 6, 4, 900, 4, 3, 32,
+    rc = lib.rac_sampling4d_fwd(one, hw, 4, p8, p8, p8, p8, p8, p8, p8, p8, None, None, None, 144, 3, 1536, 1, 8, 6, 4, 900, 4, 3, 32,
                                 pc, db, 0.08, 256.0, 704.0, 1e-5, 0, None)
     assert rc == -1 and b"64 channels" in lib.rac_last_error()
     rc = lib.rac_sasa_fwd(p8, p8, p8, None, p8, 776, 8, 1, 900, 8, 16, pc, None)
     assert rc == -1 and b"head dim" in lib.rac_last_error()
     rc = lib.rac_mixing_fwd(p8, p8, 1.0, p8, None, 1.0, 65536, 900, 4, 97, 64, 128, 1e-5, 0, None)
     assert rc == -1 and b"in_points" in lib.rac_last_error()
-    rc = lib.rac_bev_sampling_fwd(p8, p8, p8, p8, p8, p8, p8, p8, p8, None, 160, 5, 80, 8, 1, 8, 900, 4, 9, 5, 128, 128, 64,
+    p16 = ctypes.c_void_p(16)
+    rc = lib.rac_bev_sampling_fwd(p8, p8, p16, p8, p8, p8, p8, p8, p8, None, 160, 5, 80, 8, 1, 8, 900, 4, 9, 5, 128, 128, 64,
                                   pc, db, 0.08, 0, None)
     assert rc == -1 and b"staging roles" in lib.rac_last_error()
-    rc = lib.rac_add_ln_fwd(p8, 1, 0, 258, 1.0, None, None, p8, p8, None, p8, 258, 4, 258, 1e-5, 0, None, 1.0, 0, None)
+    rc = lib.rac_bev_sampling_fwd(p8, p8, p8, p8, p8, p8, p8, p8, p8, None, 160, 5, 80, 8, 1, 8, 900, 4, 4, 5, 128, 128, 64,
+                                  pc, db, 0.08, 0, None)
+    assert rc == -1 and b"16-byte aligned" in lib.rac_last_error()
+    rc = lib.rac_add_ln_fwd(p8, 1, 0, 258, 1.0, None, None, p8, p8, None, p8, 258, 4, 258, 1e-5, 0, None, 1.0, 0, 0, None)
     assert rc == -1 and b"dim" in lib.rac_last_error()
+    rc = lib.rac_add_ln_fwd(p8, 1, 0, 256, 1.0, None, None, p8, p8, None, p8, 256, 4, 256, 1e-5, 0, p8, 1.0, 4, 1, None)
+    assert rc == -1 and b"split_layout" in lib.rac_last_error()
     # empty problems return success before touching any pointer
     assert lib.rac_msmv_fwd(None, None, 4, None, None, None, 0, 6, 900, 12, 64, 0, 0, 1, 1, None) == 0
     assert lib.rac_bev_pool_v2_fwd(None, None, None, None, None, None, None, None, 64, 0, None) == 0

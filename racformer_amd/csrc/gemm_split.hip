@@ -327,19 +327,40 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[t][j] = (gs_f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        // X fragments one K step ahead of their MFMAs (two register sets): the LDS latency of step ks + 1 runs under the
+        // twelve MFMAs of step ks instead of in front of them
+        gs_h8 xh[2][2], xl[2][2];
+        auto frag = [&](int ks, int b) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const char *rowp = S + (16 * j + li) * 1024;
-                const gs_h8 xh = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + lk) ^ li) * 16));
-                const gs_h8 xl = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + 4 + lk) ^ li) * 16));
+                xh[b][j] = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + lk) ^ li) * 16));
+                xl[b][j] = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + 4 + lk) ^ li) * 16));
+            }
+        };
+        frag(0, 0);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t][ks], xh, acc[t][j], 0, 0, 0);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][ks], xl, acc[t][j], 0, 0, 0);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][ks], xh, acc[t][j], 0, 0, 0);
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 1 < 8)
+                frag(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the four reads above the MFMAs: hipcc otherwise sinks them to their uses)
+            // product-major: four independent accumulators between two MFMAs into the same one (back-to-back dependent MFMAs
+            // wait out each other's latency -- the kernel ran at half the MFMA rate)
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        if (pr == 0)
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t][ks], xh[ks & 1][j], acc[t][j], 0, 0, 0);
+                        else if (pr == 1)
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][ks], xl[ks & 1][j], acc[t][j], 0, 0, 0);
+                        else
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t][ks], xh[ks & 1][j], acc[t][j], 0, 0, 0);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (u == 0 && st + 3 < nstages)

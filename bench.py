@@ -284,6 +284,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    host_elapsed = time.perf_counter() - t0     # the host has enqueued every step (it runs ahead of the GPU unless it is the limiter)
     fence()
     elapsed = time.perf_counter() - t0
     timer, _lib.timer = _lib.timer, _lib.KernelTimer()
@@ -358,6 +359,8 @@ def main():
         "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "per_rank_ms_per_step": per_rank_ms,
+        # host-side time to enqueue one step (Python + launches, rank 0): close to ms_per_step means the host is the limiter
+        "host_enqueue_ms_per_step": 1e3 * host_elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if fdt == torch.float32 else "bf16-features/f32-math", "data": "synthetic",
         "arithmetic_note": "fp32 storage and fp32-accurate results throughout; the largest contractions run on the 16-bit "

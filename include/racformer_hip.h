@@ -34,6 +34,7 @@
  *   rac_decode_fwd    <- NMSFreeCoder.decode_single + get_bboxes, models/bbox/coders/nms_free_coder.py:37-88,
  *                        models/racformer_head.py:488-507
  *   rac_outproj_fwd / rac_gemm_split_pack_fwd <- AdaptiveMixing.out_proj (nn.Linear 32768 -> 256), models/racformer_transformer.py:566,606
+ *   rac_value_proj_fwd <- BEVSelfAttention.value_proj over the BEV maps, models/bev_self_attention.py:162-174
  *   rac_generator_fwd <- AdaptiveMixing.parameter_generator (nn.Linear 256 -> 65536), models/racformer_transformer.py:565,589
  *   rac_rowgemm_fwd   <- nn.Linear + its preceding add / LayerNorm / ReLU groups, models/racformer_transformer.py:170-177, 243-269
  *   rac_gru_gate_fwd / rac_upsample2x_fwd <- ConvGRUCell.forward's element-wise tail, nn.Upsample
@@ -259,6 +260,17 @@ int rac_outproj_fwd(const void *z_image, const void *w_image, float *partials, i
  *   out     : device f32, row m at out + m*ld_out;  K % 32 == 0, ld_out % 4 == 0, N % 4 == 0 unless K == 256 */
 int rac_generator_fwd(const void *x_image, const void *w_image, const float *bias, float alpha, float *out, int64_t ld_out, int M,
                       int N, int K, void *stream);
+
+/* BEVSelfAttention.value_proj over a whole BEV stream (nn.Linear(256 -> 256) on every pixel of every frame,
+ * models/bev_self_attention.py:162-174) read straight from the channel-first maps:
+ *     out[f*HW + p][n] = sum_c x[f][c][p] * W[n][c] + add[p][n]        (add NULL: + bias[n], bias NULL: nothing)
+ *   x       : device f32 [frames][256][HW] (the reference's [B*T, C, H, W]);  HW % 32 == 0
+ *   w_image : device f16 line image [256][8][hi 32 | lo 32] (rac_gemm_split_pack_fwd with scale 2^s); w_alpha = 2^-s
+ *   add     : device f32 [HW][256] -- the frame-independent term value_proj(pos) + bias -- or NULL;  bias: device f32 [256] or NULL
+ *   out     : device f32 [frames*HW][256] (= [B*T, H*W, heads, 64], the value operand of rac_bev_sampling_fwd)
+ * Split-precision f16 MFMA (hi / lo per operand, fp32 accumulate), activation scale per pixel.  16-byte aligned pointers. */
+int rac_value_proj_fwd(const float *x, const void *w_image, float w_alpha, const float *add, const float *bias, float *out,
+                       int frames, int channels, int HW, int features, void *stream);
 
 /* The temporal-fusion convolution of RadarBEVTemporalEncoder (3x3, stride 1, pad 1, Cin -> 256; the 193-GFLOP
  * nn.Conv2d of models/racformer_transformer.py:631,655) as an implicit GEMM on the f16 matrix cores with

@@ -40,6 +40,7 @@ SIGNATURES = {
     "rac_decode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _i, _vp]),
     "rac_rowgemm_fwd": (_i, [_vp, _i, _i, _vp]),
     "rac_gemm_split_pack_fwd": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "rac_value_proj_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rac_outproj_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rac_generator_fwd": (_i, [_vp, _vp, _vp, _f, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
     "rac_gru_gate_fwd": (_i, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
@@ -91,7 +92,13 @@ def check(rc, what):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current stream on the current device, as the raw hipStream_t the C-ABI takes.  Through the C bindings
+    directly: torch.cuda.current_stream() builds a Stream object (9 us a call -- a fifth of the host time of a decode step,
+    which issues ~140 launches)."""
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:      # (private bindings: fall back to the public API if a torch release renames them)
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def dtype_code(t):

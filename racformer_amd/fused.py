@@ -590,6 +590,27 @@ def pack_gemm_split_weight(weight):
     return img, 2.0 ** (-s) / SPLIT_ACT_SCALE
 
 
+def value_proj_fused(maps, w_image, w_alpha, add=None, bias=None):
+    """maps f32 [F, 256, H, W] (channel-first BEV maps), w_image f16 [256, 8, 64] (pack_gemm_split_weight), w_alpha = 2^-s of the
+    image, add f32 [H*W, 256] (frame-independent term) or bias [256] -> f32 [F, H*W, 256] = maps^T @ W^T + add (rac_value_proj_fwd)."""
+    _lib.require_gpu(maps, w_image, what="value_proj_fused")
+    F_, C, H, W = maps.shape
+    if maps.dtype != torch.float32 or not maps.is_contiguous() or w_image.dtype != torch.float16 or tuple(w_image.shape) != (256, 8, 64):
+        raise RuntimeError("value_proj_fused: maps must be contiguous float32 [F,256,H,W], w_image f16 [256,8,64]")
+    if add is not None and (add.dtype != torch.float32 or not add.is_contiguous() or tuple(add.shape) != (H * W, 256)):
+        raise RuntimeError("value_proj_fused: add must be a contiguous float32 [H*W, 256] tensor")
+    out = torch.empty(F_, H * W, 256, device=maps.device, dtype=torch.float32)
+    ev = _lib.timer.record("value_proj_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_value_proj_fwd(_lib.ptr(maps), _lib.ptr(w_image), float(w_alpha), _lib.ptr(add) if add is not None else None,
+                                       _lib.ptr(bias) if bias is not None else None, _lib.ptr(out), F_, C, H * W, 256, _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_value_proj_fwd")
+    return out
+
+
 def generator_fused(x_image, w_image, bias, alpha, timer_name="mixing_generator_gemm", ld_out=None):
     """x_image f16 [M, K/32 * 64] (row_seg(split_lines=True) / add_ln(split_lines=True)), w_image f16 [N, K/32, 64] -> fp32 [M, N] =
     alpha * X @ W^T + bias (rac_generator_fwd), one launch."""

@@ -29,7 +29,7 @@ from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add
                     generator_fused, gru_gate_fused, layer_boundary_fused, mixing_fused, outproj_fused, pack_conv3x3_weight,
                     pack_gemm_split_weight,
                     pe_head, refine_fused, row_gemm,
-                    row_seg, rowgemm_launch, sampling4d_fused, sasa_fused, split_weight_f16, upsample2x_fused)
+                    row_seg, rowgemm_launch, sampling4d_fused, sasa_fused, split_weight_f16, upsample2x_fused, value_proj_fused)
 from .msda import msda_forward
 from .msmv import msmv_forward
 
@@ -941,7 +941,18 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             lvp, lpe = lbs.attention.value_proj, lbs.positional_encoding
             pos_term = self._cached(f"lss_pos_term_{Hl}x{Wl}", [lvp.weight, lvp.bias, lpe.row_embed.weight, lpe.col_embed.weight],
                                     lambda: lvp(lpe.grid(Hl, Wl).to(lvp.weight.dtype).reshape(-1, Hl * Wl).t()).contiguous())
-            lss_value, lss_hw = lbs.attention.project_value(lss_bev_feats, pos_term=pos_term), (Hl, Wl)
+            Bl, Tl, Cl = lss_bev_feats.shape[:3]
+            vp_img = self._cached("lss_vp_img", [lvp.weight], lambda: pack_gemm_split_weight(lvp.weight)) \
+                if Cl == 256 and lvp.weight.shape[0] == 256 and (Hl * Wl) % 32 == 0 and lss_bev_feats.dtype == torch.float32 \
+                else (None, None)
+            if vp_img[0] is not None:
+                # hand-written split-precision GEMM straight from the channel-first maps (transpose, hi / lo split and the
+                # positional term inside the kernel); alpha of the pack carries 1 / SPLIT_ACT_SCALE, which this kernel does not use
+                lss_value = value_proj_fused(lss_bev_feats.reshape(Bl * Tl, Cl, Hl, Wl).contiguous(), vp_img[0], vp_img[1] * SPLIT_ACT_SCALE,
+                                             add=pos_term).view(Bl * Tl, Hl * Wl, lbs.attention.num_heads, -1)
+            else:
+                lss_value = lbs.attention.project_value(lss_bev_feats, pos_term=pos_term)
+            lss_hw = (Hl, Wl)
         else:
             lss_value, lss_hw = lbs.prepare_value(lss_bev_feats)
         radar_value, radar_hw = self.sampling_radar_bev.prepare_value(radar_bev_feats, conv_pack)

@@ -445,3 +445,36 @@ def test_conv3x3_stride2_kernel(shape):
         else:
             want, tol = conv.to(DEV)(xg).double().cpu(), 2e-5
     assert (got.double().cpu() - want).abs().max().item() <= tol * want.abs().max().item()
+
+
+@pytest.mark.parametrize("F_,H,W", [(8, 128, 128), (3, 16, 16), (1, 8, 4)])
+def test_value_proj_kernel_vs_float64(F_, H, W):
+    """rac_value_proj_fwd (transpose + per-pixel hi / lo split + split-precision GEMM + additive term in one kernel) against
+    float64, with channels and pixels of very different magnitude (the activation scale is chosen per pixel), an all-zero
+    pixel, and against the fp32 library formulation it replaces."""
+    from racformer_amd.fused import SPLIT_ACT_SCALE, pack_gemm_split_weight, value_proj_fused
+    g = torch.Generator().manual_seed(F_ * H + W)
+    lin = torch.nn.Linear(256, 256)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(256, 256, generator=g) * 0.06)
+        lin.bias.copy_(torch.randn(256, generator=g))
+    lin = lin.to(DEV)
+    x = torch.randn(F_, 256, H, W, generator=g)
+    x *= torch.exp(torch.randn(F_, 1, H, W, generator=g) * 3.0)          # pixels spanning orders of magnitude
+    x[:, ::7] *= 1e-3                                                    # weak channels next to strong ones
+    x[0, :, 0, 0] = 0.0
+    x = x.to(DEV)
+    add = torch.randn(H * W, 256, generator=g).to(DEV)
+    w_img, alpha = pack_gemm_split_weight(lin.weight)
+    got = value_proj_fused(x, w_img, alpha * SPLIT_ACT_SCALE, add=add)
+    a = x.reshape(F_, 256, H * W).transpose(1, 2)
+    want = a.double() @ lin.weight.double().t() + add.double()
+    ref32 = torch.baddbmm(add.unsqueeze(0).expand(F_, H * W, 256), a, lin.weight.t().unsqueeze(0).expand(F_, 256, 256))
+    # error relative to each pixel's own magnitude (rows differ by orders of magnitude)
+    scale = a.abs().amax(-1, keepdim=True).double().clamp_min(1e-30)
+    e_split = ((got.double() - want).abs() / scale).max().item()
+    e_fp32 = ((ref32.double() - want).abs() / scale).max().item()
+    assert tuple(got.shape) == (F_, H * W, 256) and e_split < 4 * e_fp32 + 1e-7, (e_split, e_fp32)
+    assert torch.equal(got[0, 0], add[0])                                # the all-zero pixel: exactly the additive term
+    got_b = value_proj_fused(x, w_img, alpha * SPLIT_ACT_SCALE, bias=lin.bias)
+    assert ((got_b.double() - (want - add.double() + lin.bias.double())).abs() / scale).max().item() < 4 * e_fp32 + 1e-6

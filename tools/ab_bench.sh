@@ -14,7 +14,7 @@ for lib in "$@"; do
   python3 - <<PY
 import json
 d=json.load(open("$out/$name.json")); r=d["roofline"]
-print("$name", "samples/s", round(d["value"],2), "s4d_us", round(r["avg_launch_ms"]*1e3,1), "bev_us", round(r["bev_sampling"]["avg_launch_ms"]*1e3,1), " ".join(f"{k}={v['avg_launch_ms']*1e3:.1f}" for k,v in d["mfma"].items()))
+print("$name", "samples/s", round(d["value"],2), "host_ms", round(d.get("host_enqueue_ms_per_step",0),2), "s4d_us", round(r["avg_launch_ms"]*1e3,1), "bev_us", round(r["bev_sampling"]["avg_launch_ms"]*1e3,1), " ".join(f"{k}={v['avg_launch_ms']*1e3:.1f}" for k,v in d["mfma"].items()))
 PY
   if [ -n "$extra" ]; then unset "${extra%%=*}"; fi
 done

@@ -235,15 +235,27 @@ __global__ __launch_bounds__(256) void sasa_mfma_kernel(const SasaArgs a)
     const int ntiles = (Q + 15) >> 4;
     sasa_f4 sc[SASA_NT];
     float mloc = -INFINITY;
+    // K rows one tile ahead of their MFMAs (two register sets; the loads of tile jt + 1 are pinned above the MFMAs of tile
+    // jt): without this every tile waited out its own L2 latency -- 15 round trips per wave
+    auto load_k = [&](int jt, rac_f4 &k0, rac_f4 &k1) {
+        const int tile = wave + 4 * jt;
+        const int key = tile * 16 + li;
+        const int kc = key < Q ? key : Q - 1;
+        const float *kp = a.qkv + (tok + kc) * ld + (H + h) * SASA_D + 4 * lk;
+        k0 = rac_ld4(kp);
+        k1 = rac_ld4(kp + 16);
+    };
+    rac_f4 kb[2][2];
+    load_k(0, kb[0][0], kb[0][1]);
 #pragma unroll
     for (int jt = 0; jt < SASA_NT; ++jt) {
         const int tile = wave + 4 * jt;
         sc[jt] = (sasa_f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (jt + 1 < SASA_NT)
+            load_k(jt + 1, kb[(jt + 1) & 1][0], kb[(jt + 1) & 1][1]);     // (clamped to a valid row past the end)
+        __builtin_amdgcn_sched_barrier(0);
         if (tile < ntiles) {
-            const int key = tile * 16 + li;
-            const int kc = key < Q ? key : Q - 1;
-            const float *kp = a.qkv + (tok + kc) * ld + (H + h) * SASA_D + 4 * lk;
-            const rac_f4 k0 = rac_ld4(kp), k1 = rac_ld4(kp + 16);
+            const rac_f4 k0 = kb[jt & 1][0], k1 = kb[jt & 1][1];
             sasa_f4 acc = {0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qb4[0].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qb4[0].y, acc, 0, 0, 0);
@@ -288,23 +300,31 @@ __global__ __launch_bounds__(256) void sasa_mfma_kernel(const SasaArgs a)
         sred[64 + wave * 16 + li] = lsum;
     // O^T[ch][query] = sum_keys V[key][ch] * P^T[key][query]
     sasa_f4 oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // (V rows one tile ahead as well)
+    auto load_v = [&](int jt, float (&va)[2][4]) {
+        const int tile = wave + 4 * jt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = tile * 16 + 4 * lk + i;
+            const int kc = key < Q ? key : Q - 1;
+            const float *vp = a.qkv + (tok + kc) * ld + (2 * H + h) * SASA_D;
+            va[0][i] = vp[li];
+            va[1][i] = vp[16 + li];
+        }
+    };
+    float vb[2][2][4];
+    load_v(0, vb[0]);
 #pragma unroll
     for (int jt = 0; jt < SASA_NT; ++jt) {
         const int tile = wave + 4 * jt;
+        if (jt + 1 < SASA_NT)
+            load_v(jt + 1, vb[(jt + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
         if (tile < ntiles) {
-            float va[2][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int key = tile * 16 + 4 * lk + i;
-                const int kc = key < Q ? key : Q - 1;
-                const float *vp = a.qkv + (tok + kc) * ld + (2 * H + h) * SASA_D;
-                va[0][i] = vp[li];
-                va[1][i] = vp[16 + li];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[0][i], sc[jt][i], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[1][i], sc[jt][i], oacc[1], 0, 0, 0);
+                oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[jt & 1][0][i], sc[jt][i], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[jt & 1][1][i], sc[jt][i], oacc[1], 0, 0, 0);
             }
         }
     }

@@ -27,7 +27,7 @@ def main():
     out = {"_source_sha": {rel: hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16] for rel in SOURCES
                            if os.path.exists(os.path.join(ROOT, rel))}}
     for k in sorted(set(fetch) | set(write)):
-        if not any(s in k for s in ("sampling4d", "bev_sampling", "msmv_fwd", "msda_fwd", "regroup", "sasa", "mixing", "conv3x3", "conv_pack", "rowgemm", "absmax", "generator", "gemm_split", "decode")):
+        if not any(s in k for s in ("sampling4d", "bev_sampling", "msmv_fwd", "msda_fwd", "regroup", "sasa", "mixing", "conv3x3", "conv_pack", "rowgemm", "absmax", "generator", "gemm_split", "decode", "value_proj")):
             continue
         f = fetch.get(k, [])
         w = write.get(k, [])

@@ -10,8 +10,10 @@
 // channels per lane (16-byte loads; one wave-instruction = four 256-byte head rows).  Points
 // are unrolled by 4 so 16 tap loads are in flight per lane.  The four items of a wave are
 // consecutive heads of one query, so the wave stores one contiguous 1 KiB output row.
-// Locations/weights are staged through LDS once per workgroup; blocks are mapped so that all
-// workgroups of one BEV frame (one `bs` index, 16.8 MB of value) run on one XCD.
+// The bilinear footprint of a point is computed once (one thread per point, into an LDS tap table of four byte
+// offsets + four weights), the taps are buffer-descriptor loads whose range check zero-fills taps outside the map,
+// the accumulation is packed FMAs; blocks are mapped so that all workgroups of one BEV frame (one `bs` index,
+// 16.8 MB of value) run on one XCD.
 #include "rac_common.h"
 
 struct MsdaArgs {
@@ -23,17 +25,31 @@ struct MsdaArgs {
     long start[RAC_MAX_LEVELS];
     int bs, keys, heads, dim, Q, L, P;
     int blocks_per_b;
+    unsigned value_bytes;   // size of the value buffer (the buffer descriptor's range; dim = 64 path)
 };
 
 #define MSDA_ITEMS 16 /* items per 256-thread workgroup: 4 waves x 4 sixteen-lane groups */
 
+#define MSDA_TAP_OUTSIDE 0x80000000u   /* tap offset past the end of the value buffer: the buffer load returns zeros */
+typedef float msda_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int msda_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int msda_u4 __attribute__((ext_vector_type(4)));
+
+// Four channels of one tap through a buffer descriptor: its range check stands in for the four branches of the bilinear
+// footprint (a tap outside the map carries the offset MSDA_TAP_OUTSIDE and reads as zero).
 template <typename FT>
-__device__ __forceinline__ rac_f4 msda_tap(const FT *base, long pix, int stride, bool ok)
+__device__ __forceinline__ rac_f4 msda_tap(__amdgpu_buffer_rsrc_t rsrc, unsigned off);
+template <>
+__device__ __forceinline__ rac_f4 msda_tap<float>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
 {
-    rac_f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok)
-        v = rac_ld4(base + pix * stride);
-    return v;
+    return __builtin_bit_cast(rac_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ rac_f4 msda_tap<unsigned short>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+{
+    const msda_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);    // 4 x bf16
+    return (rac_f4){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                    __uint_as_float(r.y & 0xffff0000u)};
 }
 
 template <typename FT>
@@ -44,6 +60,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d64_kernel(const MsdaArgs a)
     const int lane = tid & 63, c4 = lane & 15;
     const int grp = tid >> 4;  // 0..15: item within the workgroup
     const int LP = a.L * a.P;
+    const int LPp = (LP + 3) & ~3;   // an item's tap list, padded to whole batches of 4 with zero-weight outside taps
 
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
@@ -55,64 +72,69 @@ __global__ __launch_bounds__(256) void msda_fwd_d64_kernel(const MsdaArgs a)
     const int nitems = min(MSDA_ITEMS, per_b - i0);
     const size_t item0 = (size_t)b * per_b + i0;
 
-    float *sloc = smem;                          // [items][L*P][2]
-    float *sattn = smem + MSDA_ITEMS * LP * 2;   // [items][L*P]
-    {
-        const float *gl = a.loc + item0 * LP * 2;
-        const float *ga = a.attn + item0 * LP;
-        for (int i = tid; i < nitems * LP * 2; i += 256)
-            sloc[i] = gl[i];
-        for (int i = tid; i < nitems * LP; i += 256)
-            sattn[i] = ga[i];
+    // tap table [items][LPp][8]: per point 4 tap byte offsets into the value buffer (MSDA_TAP_OUTSIDE = outside the map) and 4
+    // bilinear weights with the attention weight folded in -- one thread per point builds it from the op's location / weight
+    // rows, instead of each of the 16 lanes that gather the point
+    float *stab = smem;
+    const unsigned key_bytes = (unsigned)(a.heads * 64 * sizeof(FT));       // one key: heads x 64 channels
+    for (int i = tid; i < nitems * LPp; i += 256) {
+        const int it = i / LPp, lp = i - it * LPp;
+        msda_u4 off = {MSDA_TAP_OUTSIDE, MSDA_TAP_OUTSIDE, MSDA_TAP_OUTSIDE, MSDA_TAP_OUTSIDE};
+        rac_f4 w4 = {0.f, 0.f, 0.f, 0.f};
+        if (lp < LP) {
+            const int l = lp / a.P;
+            const int H = a.H[l], W = a.W[l];
+            const float *gl = a.loc + ((item0 + it) * LP + lp) * 2;
+            const float x = gl[0], y = gl[1];
+            const float at = a.attn[(item0 + it) * LP + lp];
+            const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
+            const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+            const int h = (i0 + it) % a.heads;
+            const unsigned base = ((unsigned)((long)b * a.keys + a.start[l]) * (unsigned)a.heads + (unsigned)h) * (unsigned)(64 * sizeof(FT));
+            off.x = t_ok && l_ok ? base + (unsigned)(h_low * W + w_low) * key_bytes : MSDA_TAP_OUTSIDE;
+            off.y = t_ok && r_ok ? base + (unsigned)(h_low * W + w_high) * key_bytes : MSDA_TAP_OUTSIDE;
+            off.z = b_ok && l_ok ? base + (unsigned)(h_high * W + w_low) * key_bytes : MSDA_TAP_OUTSIDE;
+            off.w = b_ok && r_ok ? base + (unsigned)(h_high * W + w_high) * key_bytes : MSDA_TAP_OUTSIDE;
+            w4 = (rac_f4){hh * hw * at, hh * lw * at, lh * hw * at, lh * lw * at};
+        }
+        *reinterpret_cast<msda_u4 *>(stab + i * 8) = off;
+        *reinterpret_cast<rac_f4 *>(stab + i * 8 + 4) = w4;
     }
     __syncthreads();
     if (grp >= nitems)
         return;
-    const int h = (i0 + grp) % a.heads;
-    const int stride = a.heads * 64;  // elements between neighbouring keys
-    const float *lp = sloc + grp * LP * 2;
-    const float *ap = sattn + grp * LP;
-
-    rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < a.L; ++l) {
-        const int H = a.H[l], W = a.W[l];
-        const FT *base = (const FT *)a.value + (((size_t)b * a.keys + a.start[l]) * a.heads + h) * 64 + c4 * 4;
-        for (int p0 = 0; p0 < a.P; p0 += 4) {
-            rac_f4 v[4][4];
-            float tw[4][4];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0, a.value_bytes, 0x00020000);
+    const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
+    const float *e = stab + grp * LPp * 8;      // same address for the 16 lanes of the group
+    msda_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    for (int p0 = 0; p0 < LPp; p0 += 4) {       // 4 points = 16 taps in flight per lane; per tap one add, one load, two packed FMAs
+        rac_f4 v[4][4], tw[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int p = p0 + k;
-                const bool act = p < a.P;
-                const int pp = act ? p : a.P - 1;
-                const float x = lp[(l * a.P + pp) * 2], y = lp[(l * a.P + pp) * 2 + 1];
-                const float at = act ? ap[l * a.P + pp] : 0.f;
-                const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
-                const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                const float hf = floorf(h_im), wf = floorf(w_im);
-                const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
-                const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-                v[k][0] = msda_tap(base, (long)h_low * W + w_low, stride, t_ok && l_ok);
-                v[k][1] = msda_tap(base, (long)h_low * W + w_high, stride, t_ok && r_ok);
-                v[k][2] = msda_tap(base, (long)h_high * W + w_low, stride, b_ok && l_ok);
-                v[k][3] = msda_tap(base, (long)h_high * W + w_high, stride, b_ok && r_ok);
-                tw[k][0] = hh * hw * at;
-                tw[k][1] = hh * lw * at;
-                tw[k][2] = lh * hw * at;
-                tw[k][3] = lh * lw * at;
-            }
+        for (int k = 0; k < 4; ++k) {
+            const msda_u4 o = *reinterpret_cast<const msda_u4 *>(e + (p0 + k) * 8);
+            tw[k] = *reinterpret_cast<const rac_f4 *>(e + (p0 + k) * 8 + 4);
+            v[k][0] = msda_tap<FT>(rsrc, o.x + lane_off);
+            v[k][1] = msda_tap<FT>(rsrc, o.y + lane_off);
+            v[k][2] = msda_tap<FT>(rsrc, o.z + lane_off);
+            v[k][3] = msda_tap<FT>(rsrc, o.w + lane_off);
+        }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                acc.x += tw[k][0] * v[k][0].x + tw[k][1] * v[k][1].x + tw[k][2] * v[k][2].x + tw[k][3] * v[k][3].x;
-                acc.y += tw[k][0] * v[k][0].y + tw[k][1] * v[k][1].y + tw[k][2] * v[k][2].y + tw[k][3] * v[k][3].y;
-                acc.z += tw[k][0] * v[k][0].z + tw[k][1] * v[k][1].z + tw[k][2] * v[k][2].z + tw[k][3] * v[k][3].z;
-                acc.w += tw[k][0] * v[k][0].w + tw[k][1] * v[k][1].w + tw[k][2] * v[k][2].w + tw[k][3] * v[k][3].w;
+        for (int k = 0; k < 4; ++k) {
+            const float w4[4] = {tw[k].x, tw[k].y, tw[k].z, tw[k].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const msda_f2 w2 = {w4[c], w4[c]};
+                acc01 = __builtin_elementwise_fma((msda_f2){v[k][c].x, v[k][c].y}, w2, acc01);
+                acc23 = __builtin_elementwise_fma((msda_f2){v[k][c].z, v[k][c].w}, w2, acc23);
             }
         }
     }
-    *reinterpret_cast<rac_f4 *>(a.out + (item0 + grp) * 64 + c4 * 4) = acc;
+    *reinterpret_cast<rac_f4 *>(a.out + (item0 + grp) * 64 + c4 * 4) = (rac_f4){acc01.x, acc01.y, acc23.x, acc23.y};
 }
 
 template <typename FT>
@@ -188,8 +210,10 @@ extern "C" int rac_msda_fwd(const void *value, const int64_t *shapes, const int6
     a.bs = bs; a.keys = keys; a.heads = heads; a.dim = dim; a.Q = Q; a.L = L; a.P = P;
     a.blocks_per_b = (Q * heads + MSDA_ITEMS - 1) / MSDA_ITEMS;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)MSDA_ITEMS * L * P * 3 * sizeof(float);
-    if (dim == 64 && P >= 1 && lds <= 48 * 1024) {
+    const size_t lds = (size_t)MSDA_ITEMS * ((L * P + 3) & ~3) * 8 * sizeof(float);
+    const size_t value_bytes = (size_t)bs * keys * heads * dim * (dtype == RAC_F32 ? 4 : 2);
+    a.value_bytes = (unsigned)value_bytes;
+    if (dim == 64 && P >= 1 && lds <= 64 * 1024 && value_bytes < (size_t)MSDA_TAP_OUTSIDE) {   // (larger values: 31-bit tap offsets do not reach)
         const int nb = 8 * ((bs + 7) / 8) * a.blocks_per_b;
         if (dtype == RAC_F32)
             hipLaunchKernelGGL(msda_fwd_d64_kernel<float>, dim3(nb), dim3(256), lds, st, a);

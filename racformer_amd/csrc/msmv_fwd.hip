@@ -13,8 +13,9 @@
 //    256-byte pixel rows (1 KiB).  A wave64 walks the P points of one (slot, query) row four at
 //    a time; all 4 levels x 4 taps = 16 independent loads are in flight per lane before the
 //    first FMA.  No cross-lane reduction is needed: the reduction over levels/taps is in-register.
-//  * per-row sampling locations / scale weights are staged once per workgroup through LDS
-//    (coalesced global read, broadcast LDS reads inside each 16-lane group).
+//  * the bilinear footprint of a point is computed ONCE (one thread per point, into an LDS tap table: four byte
+//    offsets + four weights per level), not by each of the 16 lanes that gather it; the taps are buffer-descriptor
+//    loads whose range check zero-fills taps outside the map (no branches), the accumulation is packed FMAs.
 //  * block -> (slot, query block) mapping is XCD-aware: blocks b and b+8 share an XCD (and its
 //    4 MiB L2), so XCD x walks slots x, x+8, ... and the 32 CUs of one XCD work on the same
 //    slot's 23 MB pyramid at the same time, neighbouring queries (adjacent rays) together.
@@ -27,6 +28,7 @@ struct MsmvArgs {
     const void *feat[RAC_MAX_LEVELS];
     int H[RAC_MAX_LEVELS];
     int W[RAC_MAX_LEVELS];
+    unsigned feat_bytes[RAC_MAX_LEVELS];   // size of each level's buffer (the buffer descriptors' ranges; C = 64 path)
     const float *loc;
     const float *w;
     float *out;
@@ -35,15 +37,27 @@ struct MsmvArgs {
     int blocks_per_slot;
 };
 
-#define MSMV_ROWS 4 /* (slot,query) rows per 256-thread workgroup: one per wave */
+#define MSMV_ROWS 8 /* (slot,query) rows per 256-thread workgroup: two per wave */
+#define MSMV_TAP_OUTSIDE 0x80000000u   /* tap offset past the end of a level's buffer: the buffer load returns zeros */
+typedef float msmv_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int msmv_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int msmv_u4 __attribute__((ext_vector_type(4)));
 
+// Four channels of one tap through the level's buffer descriptor: its range check stands in for the four branches of the
+// bilinear footprint (a tap outside the map carries the offset MSMV_TAP_OUTSIDE and reads as zero).
 template <typename FT>
-__device__ __forceinline__ rac_f4 msmv_tap(const FT *base, int h, int w, int W, bool ok)
+__device__ __forceinline__ rac_f4 msmv_tap(__amdgpu_buffer_rsrc_t rsrc, unsigned off);
+template <>
+__device__ __forceinline__ rac_f4 msmv_tap<float>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
 {
-    rac_f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok)
-        v = rac_ld4(base + ((size_t)h * W + w) * 64);
-    return v;
+    return __builtin_bit_cast(rac_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ rac_f4 msmv_tap<unsigned short>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+{
+    const msmv_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);    // 4 x bf16
+    return (rac_f4){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                    __uint_as_float(r.y & 0xffff0000u)};
 }
 
 template <typename FT, int L, bool OUT_CL>
@@ -62,83 +76,96 @@ __global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(con
     const int q0 = (j % a.blocks_per_slot) * MSMV_ROWS;
     const int nrows = min(MSMV_ROWS, a.Q - q0);
 
-    float *sloc = smem;                      // [rows][P][3]
-    float *sw = smem + MSMV_ROWS * P * 3;    // [rows][P][L]
+    // tap table [L][rows*P][8]: per point and level the 4 tap byte offsets into the level's buffer (MSMV_TAP_OUTSIDE =
+    // outside the map) and the 4 bilinear weights with the level's scale weight folded in -- one thread per point builds it
+    // from the op's loc / weight rows, instead of each of the 16 lanes that gather the point
+    float *stab = smem;
+    const int lstride = MSMV_ROWS * P * 8;
     const size_t row0 = (size_t)s * a.Q + q0;
-    {
-        const float *gl = a.loc + row0 * P * 3;
-        const float *gw = a.w + row0 * P * L;
-        for (int i = tid; i < nrows * P * 3; i += 256)
-            sloc[i] = gl[i];
-        for (int i = tid; i < nrows * P * L; i += 256)
-            sw[i] = gw[i];
-    }
-    __syncthreads();
-    if (wave >= nrows)
-        return;
-    const int q = q0 + wave;
-
-    size_t out_row;  // element offset of this row's output block
-    if (OUT_CL) {
-        const int g = s % a.G, t = (s / a.G) % a.T, b = s / (a.G * a.T);
-        out_row = ((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * (size_t)P * 64;
-    } else {
-        out_row = ((size_t)s * a.Q + q) * 64 * (size_t)P;
-    }
-
-    for (int p0 = 0; p0 < P; p0 += 4) {
-        const int p = p0 + sub;
-        const bool act = p < P;
-        const int pp = act ? p : P - 1;
-        const float *lp = sloc + (wave * P + pp) * 3;
-        const float *wp = sw + (wave * P + pp) * L;
+    for (int i = tid; i < nrows * P; i += 256) {
+        const float *lp = a.loc + (row0 * P + i) * 3;
+        const float *wp = a.w + (row0 * P + i) * L;
         const float lu = lp[0], lv = lp[1];
         int view = (int)roundf(lp[2] * (float)(a.N - 1));
         view = min(max(view, 0), a.N - 1);
-
-        rac_f4 v[L][4];
-        float tw[L][4];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int H = a.H[l], W = a.W[l];
             const float h_im = lv * (float)(H - 1);
             const float w_im = lu * (float)(W - 1);
-            const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
             const float hf = floorf(h_im), wf = floorf(w_im);
             const int h_low = (int)hf, w_low = (int)wf;
             const int h_high = h_low + 1, w_high = w_low + 1;
             const float lh = h_im - hf, lw = w_im - wf;
             const float hh = 1.f - lh, hw = 1.f - lw;
-            const FT *base = (const FT *)a.feat[l] + ((size_t)s * a.N + view) * H * W * 64 + c4 * 4;
             const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
             const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-            v[l][0] = msmv_tap(base, h_low, w_low, W, t_ok && l_ok);
-            v[l][1] = msmv_tap(base, h_low, w_high, W, t_ok && r_ok);
-            v[l][2] = msmv_tap(base, h_high, w_low, W, b_ok && l_ok);
-            v[l][3] = msmv_tap(base, h_high, w_high, W, b_ok && r_ok);
-            tw[l][0] = hh * hw;
-            tw[l][1] = hh * lw;
-            tw[l][2] = lh * hw;
-            tw[l][3] = lh * lw;
-        }
-        rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
+            const unsigned pix_bytes = (unsigned)(64 * sizeof(FT));
+            const unsigned mbase = (unsigned)(s * a.N + view) * (unsigned)(H * W) * pix_bytes;   // map (slot, camera) of the level
+            msmv_u4 off;
+            off.x = t_ok && l_ok ? mbase + (unsigned)(h_low * W + w_low) * pix_bytes : MSMV_TAP_OUTSIDE;
+            off.y = t_ok && r_ok ? mbase + (unsigned)(h_low * W + w_high) * pix_bytes : MSMV_TAP_OUTSIDE;
+            off.z = b_ok && l_ok ? mbase + (unsigned)(h_high * W + w_low) * pix_bytes : MSMV_TAP_OUTSIDE;
+            off.w = b_ok && r_ok ? mbase + (unsigned)(h_high * W + w_high) * pix_bytes : MSMV_TAP_OUTSIDE;
             const float wl = wp[l];
-            acc.x += (tw[l][0] * v[l][0].x + tw[l][1] * v[l][1].x + tw[l][2] * v[l][2].x + tw[l][3] * v[l][3].x) * wl;
-            acc.y += (tw[l][0] * v[l][0].y + tw[l][1] * v[l][1].y + tw[l][2] * v[l][2].y + tw[l][3] * v[l][3].y) * wl;
-            acc.z += (tw[l][0] * v[l][0].z + tw[l][1] * v[l][1].z + tw[l][2] * v[l][2].z + tw[l][3] * v[l][3].z) * wl;
-            acc.w += (tw[l][0] * v[l][0].w + tw[l][1] * v[l][1].w + tw[l][2] * v[l][2].w + tw[l][3] * v[l][3].w) * wl;
+            float *e = stab + l * lstride + i * 8;
+            *reinterpret_cast<msmv_u4 *>(e) = off;
+            *reinterpret_cast<rac_f4 *>(e + 4) = (rac_f4){hh * hw * wl, hh * lw * wl, lh * hw * wl, lh * lw * wl};
         }
-        if (act) {
-            if (OUT_CL) {
-                *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = acc;
-            } else {
-                float *o = a.out + out_row + (size_t)(c4 * 4) * P + p;
-                o[0] = acc.x;
-                o[(size_t)P] = acc.y;
-                o[(size_t)2 * P] = acc.z;
-                o[(size_t)3 * P] = acc.w;
+    }
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rsrc[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+        rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.feat[l]), 0, a.feat_bytes[l], 0x00020000);
+    const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
+    // wave w gathers rows w, w+4 of the workgroup; per tap: one add for the lane's channel offset, one buffer load, two
+    // packed FMAs; 16 taps (4 levels x 4) in flight per lane
+    for (int row = wave; row < nrows; row += 4) {
+        const int q = q0 + row;
+        size_t out_row;  // element offset of this row's output block
+        if (OUT_CL) {
+            const int g = s % a.G, t = (s / a.G) % a.T, b = s / (a.G * a.T);
+            out_row = ((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * (size_t)P * 64;
+        } else {
+            out_row = ((size_t)s * a.Q + q) * 64 * (size_t)P;
+        }
+        for (int p0 = 0; p0 < P; p0 += 4) {
+            const int p = p0 + sub;
+            const bool act = p < P;
+            const float *e = stab + (row * P + (act ? p : P - 1)) * 8;
+            rac_f4 v[L][4], tw[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const msmv_u4 o = *reinterpret_cast<const msmv_u4 *>(e + l * lstride);
+                tw[l] = *reinterpret_cast<const rac_f4 *>(e + l * lstride + 4);
+                v[l][0] = msmv_tap<FT>(rsrc[l], o.x + lane_off);
+                v[l][1] = msmv_tap<FT>(rsrc[l], o.y + lane_off);
+                v[l][2] = msmv_tap<FT>(rsrc[l], o.z + lane_off);
+                v[l][3] = msmv_tap<FT>(rsrc[l], o.w + lane_off);
+            }
+            msmv_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const float w4[4] = {tw[l].x, tw[l].y, tw[l].z, tw[l].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const msmv_f2 w2 = {w4[c], w4[c]};
+                    acc01 = __builtin_elementwise_fma((msmv_f2){v[l][c].x, v[l][c].y}, w2, acc01);
+                    acc23 = __builtin_elementwise_fma((msmv_f2){v[l][c].z, v[l][c].w}, w2, acc23);
+                }
+            }
+            if (act) {
+                if (OUT_CL) {
+                    *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = (rac_f4){acc01.x, acc01.y, acc23.x, acc23.y};
+                } else {
+                    float *o = a.out + out_row + (size_t)(c4 * 4) * P + p;
+                    o[0] = acc01.x;
+                    o[(size_t)P] = acc01.y;
+                    o[(size_t)2 * P] = acc23.x;
+                    o[(size_t)3 * P] = acc23.y;
+                }
             }
         }
     }
@@ -200,7 +227,7 @@ template <typename FT, bool OUT_CL>
 static int launch_c64(const MsmvArgs &a, hipStream_t st)
 {
     const int nb = 8 * ((a.S + 7) / 8) * a.blocks_per_slot;
-    const size_t lds = (size_t)MSMV_ROWS * a.P * (3 + a.L) * sizeof(float);
+    const size_t lds = (size_t)MSMV_ROWS * a.P * 8 * a.L * sizeof(float);
     switch (a.L) {
     case 2: hipLaunchKernelGGL((msmv_fwd_c64_kernel<FT, 2, OUT_CL>), dim3(nb), dim3(256), lds, st, a); break;
     case 4: hipLaunchKernelGGL((msmv_fwd_c64_kernel<FT, 4, OUT_CL>), dim3(nb), dim3(256), lds, st, a); break;
@@ -231,11 +258,17 @@ extern "C" int rac_msmv_fwd(const void *const *feats, const int32_t *hw, int L, 
         a.feat[l] = feats[l];
         a.H[l] = hw[2 * l];
         a.W[l] = hw[2 * l + 1];
+        const size_t bytes = (size_t)S * N * a.H[l] * a.W[l] * C * (dtype == RAC_F32 ? 4 : 2);
+        a.feat_bytes[l] = bytes < (size_t)MSMV_TAP_OUTSIDE ? (unsigned)bytes : 0u;    // 0: too large for the 31-bit tap offsets
     }
     for (int l = L; l < RAC_MAX_LEVELS; ++l) {
         a.feat[l] = nullptr;
         a.H[l] = a.W[l] = 1;
+        a.feat_bytes[l] = 0;
     }
+    bool small_maps = true;
+    for (int l = 0; l < L; ++l)
+        small_maps = small_maps && a.feat_bytes[l] != 0;
     a.loc = loc; a.w = w; a.out = out;
     a.L = L; a.S = S; a.N = N; a.Q = Q; a.P = P; a.C = C;
     a.T = out_layout == RAC_OUT_BQGTPC ? T : 0;
@@ -243,7 +276,7 @@ extern "C" int rac_msmv_fwd(const void *const *feats, const int32_t *hw, int L, 
     a.blocks_per_slot = (Q + MSMV_ROWS - 1) / MSMV_ROWS;
     hipStream_t st = (hipStream_t)stream;
     int fell_through = 1;
-    if (C == 64 && (L == 2 || L == 4 || L == 5)) {
+    if (C == 64 && (L == 2 || L == 4 || L == 5) && small_maps && (size_t)MSMV_ROWS * P * 8 * L * sizeof(float) <= 64 * 1024) {
         if (dtype == RAC_F32)
             fell_through = out_layout == RAC_OUT_BQGTPC ? launch_c64<float, true>(a, st) : launch_c64<float, false>(a, st);
         else

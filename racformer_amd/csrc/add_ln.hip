@@ -123,6 +123,89 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ a
     }
 }
 
+// Many split-K partials (the 32 slices of the mixing's out_proj): one row per workgroup, its four waves sum a quarter of the
+// partials each (eight independent 16-byte loads in flight per lane), wave 0 adds the quarters in a fixed order and normalises.
+// 900 workgroups instead of 225: four times the loads in flight for the 29.5 MB of partials.  dim == 256 only.
+__global__ __launch_bounds__(256) void add_ln_many_kernel(const float *__restrict__ a, int S, long pstride, int ld_a, float a_scale,
+                                                          const float *__restrict__ residual, const float *__restrict__ bias,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          const float *__restrict__ post, float *__restrict__ out, int ld_out,
+                                                          int rows, float eps, int relu,
+                                                          _Float16 *__restrict__ split_out, float split_scale, int split_pad, int split_lines)
+{
+    __shared__ rac_f4 part[3][64];
+    const int row = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = (S + 3) / 4, s_lo = wave * per, s_hi = min(S, s_lo + per);
+    rac_f4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+        rac_f4 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            w[j] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+            if (s0 + j < s_hi)
+                w[j] = rac_ld4(a + (size_t)(s0 + j) * pstride + (size_t)row * ld_a + lane * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v.x += w[j].x; v.y += w[j].y; v.z += w[j].z; v.w += w[j].w;
+        }
+    }
+    if (wave > 0)
+        part[wave - 1][lane] = v;
+    __syncthreads();
+    if (wave > 0)
+        return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const rac_f4 w = part[k][lane];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
+    if (bias) {
+        const rac_f4 w = rac_ld4(bias + lane * 4);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    if (residual) {
+        const rac_f4 w = rac_ld4(residual + (size_t)row * 256 + lane * 4);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    const float mean = aln_wave_sum((v.x + v.y) + (v.z + v.w)) / 256.f;
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    const float rstd = 1.f / sqrtf(aln_wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 256.f + eps);
+    const rac_f4 g = rac_ld4(gamma + lane * 4), b = rac_ld4(beta + lane * 4);
+    rac_f4 y = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
+    if (relu) {
+        y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+    }
+    if (post) {
+        const rac_f4 w = rac_ld4(post + (size_t)row * 256 + lane * 4);
+        y.x += w.x; y.y += w.y; y.z += w.z; y.w += w.w;
+    }
+    *reinterpret_cast<rac_f4 *>(out + (size_t)row * ld_out + lane * 4) = y;
+    if (split_out) {
+        rac_h4 hi, lo;
+        rac_split_f16(y.x * split_scale, hi.x, lo.x);
+        rac_split_f16(y.y * split_scale, hi.y, lo.y);
+        rac_split_f16(y.z * split_scale, hi.z, lo.z);
+        rac_split_f16(y.w * split_scale, hi.w, lo.w);
+        if (split_lines) {
+            _Float16 *dl = split_out + (size_t)row * 512 + (lane >> 3) * 64 + (lane & 7) * 4;
+            *reinterpret_cast<rac_h4 *>(dl) = hi;
+            *reinterpret_cast<rac_h4 *>(dl + 32) = lo;
+        } else {
+            _Float16 *dst = split_out + (size_t)row * (768 + split_pad) + lane * 4;
+            *reinterpret_cast<rac_h4 *>(dst) = hi;
+            *reinterpret_cast<rac_h4 *>(dst + 256) = hi;
+            *reinterpret_cast<rac_h4 *>(dst + 512) = lo;
+            if (split_pad && lane == 0) {
+                _Float16 *pad = split_out + (size_t)row * (768 + split_pad) + 768;
+                for (int i = 0; i < split_pad; ++i)
+                    pad[i] = i < 2 ? (_Float16)split_scale : (_Float16)0.f;
+            }
+        }
+    }
+}
+
 // position-encoder head: out = relu(LN(W x + b)) for a 3-wide input (models/racformer_transformer.py:170-173);
 // a GEMM with K=3 is pure launch overhead, so the three FMAs per output are done here.
 __global__ __launch_bounds__(256) void pe_head_kernel(const float *__restrict__ x, int ld_x, const float *__restrict__ W,
@@ -163,6 +246,12 @@ extern "C" int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_
     if (rows == 0)
         return 0;
     RAC_CHECK_ARG(a && gamma && beta && out, "rac_add_ln_fwd: null pointer");
+    if (dim == 256 && num_partials >= 8) {
+        hipLaunchKernelGGL(add_ln_many_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, num_partials, (long)partial_stride, ld_a,
+                           a_scale, residual, bias, gamma, beta, post_residual, out, ld_out, rows, eps, relu,
+                           reinterpret_cast<_Float16 *>(split_out), split_scale, split_pad, split_layout == RAC_SPLIT_LINES ? 1 : 0);
+        return rac_launch_status("rac_add_ln_fwd");
+    }
     hipLaunchKernelGGL(add_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, num_partials,
                        (long)partial_stride, ld_a, a_scale, residual, bias, gamma, beta, post_residual, out, ld_out, rows, dim, eps, relu,
                        reinterpret_cast<_Float16 *>(split_out), split_scale, split_pad, split_layout == RAC_SPLIT_LINES ? 1 : 0);

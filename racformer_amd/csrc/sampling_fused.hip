@@ -166,7 +166,9 @@ __device__ __forceinline__ rac_f4 s4d_tap<unsigned short>(__amdgpu_buffer_rsrc_t
                     __uint_as_float(r.y & 0xffff0000u)};
 }
 
-template <typename FT, int L>
+// COMPACT: a row's points with no tap inside any map (no camera sees them: about half of the points of a 3-camera rig) are
+// set aside -- the gather walks only the others, four per wave-step, and the rest of the row is zero-filled by plain stores.
+template <typename FT, int L, bool COMPACT>
 __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_kernel(const S4dArgs a)
 {
     extern __shared__ float smem[];
@@ -190,6 +192,8 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
     float *stab = smem;
     const int lstride = a.rows * P * 8;
     float *sl2i = stab + L * lstride;       // [N][16]
+    unsigned char *sval = reinterpret_cast<unsigned char *>(sl2i + a.N * 16);   // [rows*P] 1: some tap of the point is inside a map
+    unsigned char *sperm = sval + a.rows * P;                                    // [rows][P] points with taps first, then the others
     for (int i = tid; i < a.N * 16; i += 256)
         sl2i[i] = a.l2i[((size_t)b * a.T + t) * a.N * 16 + i];
     __syncthreads();
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
         s4d_keypoint<L>(a, sl2i, b, t, g, q0 + r, p, loc3, wl);
         const float lu = loc3[0], lv = loc3[1];
         const int view = (int)loc3[2] & 255;
+        bool any = false;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int H = a.H[l], W = a.W[l];
@@ -219,10 +224,13 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
             off.y = t_ok && r_ok ? mbase + (unsigned)(h_low * W + w_high) * pix_bytes : S4D_TAP_OUTSIDE;
             off.z = b_ok && l_ok ? mbase + (unsigned)(h_high * W + w_low) * pix_bytes : S4D_TAP_OUTSIDE;
             off.w = b_ok && r_ok ? mbase + (unsigned)(h_high * W + w_high) * pix_bytes : S4D_TAP_OUTSIDE;
+            any = any || ((t_ok || b_ok) && (l_ok || r_ok));
             float *e = stab + l * lstride + i * 8;
             *reinterpret_cast<s4d_u4 *>(e) = off;
             *reinterpret_cast<rac_f4 *>(e + 4) = (rac_f4){hh * hw * wl[l], hh * lw * wl[l], lh * hw * wl[l], lh * lw * wl[l]};
         }
+        if (COMPACT)
+            sval[i] = any ? 1 : 0;
         if (a.loc_out) {
             float *lo = a.loc_out + (((size_t)s * a.Q + q0 + r) * P + p) * 3;
             lo[0] = lu;
@@ -247,10 +255,29 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
     for (int row = wave; row < nrows; row += 4) {
         const int q = q0 + row;
         const size_t out_row = ((((size_t)b * a.Q + q) * a.G + g) * a.T + t) * (size_t)P * 64;
-        for (int p0 = 0; p0 < P; p0 += 4) {
-            const int p = p0 + sub;
-            const bool act = p < P;
-            const float *e = stab + (row * P + (act ? p : P - 1)) * 8;
+        int nlive = P;
+        if (COMPACT) {
+            // rank the row's points inside the wave: lanes < P hold one point each (P <= 64)
+            const bool mine = lane < P && sval[row * P + lane] != 0;
+            const unsigned long long mask = __ballot(mine);
+            nlive = __popcll(mask);
+            if (lane < P) {
+                const int before = __popcll(mask & ((1ull << lane) - 1ull));
+                sperm[row * P + (mine ? before : nlive + (lane - before))] = (unsigned char)lane;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (same wave reads it back)
+            // points without any tap: zeros, four rows of 256 B per wave-step
+            for (int z0 = nlive; z0 < P; z0 += 4) {
+                if (z0 + sub < P) {
+                    const int pz = sperm[row * P + z0 + sub];
+                    *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)pz * 64 + c4 * 4) = (rac_f4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        for (int p0 = 0; p0 < nlive; p0 += 4) {
+            const bool act = p0 + sub < nlive;
+            const int p = COMPACT ? (int)sperm[row * P + (act ? p0 + sub : nlive - 1)] : (act ? p0 + sub : P - 1);
+            const float *e = stab + (row * P + p) * 8;
             rac_f4 v[L][4], tw[L];
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -331,10 +358,19 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
     a.blocks_per_slot = (Q + a.rows - 1) / a.rows;
     const int S = B * T * G;
     const int nb = 8 * ((S + 7) / 8) * a.blocks_per_slot;
-    const size_t lds = ((size_t)a.rows * P * 8 * L + (size_t)N * 16) * sizeof(float);
+    const size_t lds = ((size_t)a.rows * P * 8 * L + (size_t)N * 16) * sizeof(float) + 2 * (size_t)a.rows * P;
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_sampling4d_fwd: P=%d x L=%d too large for the LDS tap table", P, L);
     hipStream_t st = (hipStream_t)stream;
-#define S4D_LAUNCH(FT, LL) hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL>), dim3(nb), dim3(256), lds, st, a)
+    // rigs whose cameras do not cover the full circle (N <= 3 here) leave about half of the points without any tap: compact them
+#ifndef S4D_COMPACT_MAX_CAMS
+#define S4D_COMPACT_MAX_CAMS 3
+#endif
+    const bool compact = N <= S4D_COMPACT_MAX_CAMS && P <= 64;
+#define S4D_LAUNCH(FT, LL)                                                                                           \
+    do {                                                                                                             \
+        if (compact) hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL, true>), dim3(nb), dim3(256), lds, st, a);     \
+        else hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL, false>), dim3(nb), dim3(256), lds, st, a);            \
+    } while (0)
     if (dtype == RAC_F32) {
         if (L == 2) S4D_LAUNCH(float, 2); else if (L == 4) S4D_LAUNCH(float, 4); else S4D_LAUNCH(float, 5);
     } else {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/ab_bench.sh <tag> lib1.so lib2.so ...   ("default" = the in-tree build)
+# usage (GPU box): [AB_ARGS="--config f8_3cam"] tools/ab_bench.sh <tag> lib1.so lib2.so ...   ("default" = the in-tree build)
 # one short bench run per library build (RACFORMER_HIP_LIB), prints the step time and the timed kernels of each
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
@@ -10,7 +10,7 @@ for lib in "$@"; do
   name=$(basename $lib .so)${extra:+_$extra}
   if [ -n "$extra" ]; then export "$extra"; fi
   if [ "$lib" = default ]; then unset RACFORMER_HIP_LIB; else export RACFORMER_HIP_LIB=$GRAFT_REPO_ROOT/$lib; fi
-  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-stress --steps 30 > $out/$name.json 2> $out/$name.err || { echo "$name FAILED"; tail -3 $out/$name.err; exit 1; }
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-stress --steps 30 $AB_ARGS > $out/$name.json 2> $out/$name.err || { echo "$name FAILED"; tail -3 $out/$name.err; exit 1; }
   python3 - <<PY
 import json
 d=json.load(open("$out/$name.json")); r=d["roofline"]

@@ -238,13 +238,19 @@ SPLIT_BIAS_PAD = 64      # extra K columns of a split image that carry the bias 
 SPLIT_SLICE = 2048       # K slice of out_proj's split-K (16 slices of the 32768-long reduction)
 
 
-def layer_boundary_fused(proposal, delta, time_diff_safe, num_ray, pc_range, pe_linear, pe_norm):
+def layer_boundary_fused(proposal, delta, time_diff_safe, num_ray, pc_range, pe_linear, pe_norm, xy_out=None):
     """refine_fused + box_prep + pe_head for the refined boxes in one launch (rac_layer_boundary_fwd).
     -> (bbox_pred [B,Q,10], bbox_xy [B,Q,10], box_table [B,Q,8], pe_head output [B,Q,256])."""
     proposal, delta = proposal.contiguous(), delta.contiguous()
     _lib.require_gpu(proposal, delta, time_diff_safe, what="layer_boundary_fused")
     B, Q, _ = proposal.shape
-    pred, xy = torch.empty_like(proposal), torch.empty_like(proposal)
+    pred = torch.empty_like(proposal)
+    if xy_out is None:
+        xy = torch.empty_like(proposal)
+    else:
+        if tuple(xy_out.shape) != tuple(proposal.shape) or not xy_out.is_contiguous() or xy_out.dtype != torch.float32:
+            raise RuntimeError("layer_boundary_fused: xy_out must be a contiguous float32 tensor shaped like the boxes")
+        xy = xy_out
     table = torch.empty(B, Q, 8, device=proposal.device, dtype=torch.float32)
     h = torch.empty(B, Q, pe_linear.weight.shape[0], device=proposal.device, dtype=torch.float32)
     pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])

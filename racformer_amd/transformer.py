@@ -991,12 +991,13 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
                     sasa_w=sasa_w, bev_owt=bev_owt, bev_ob=bev_ob, c0r0_w=c0r0_w, c0r0_b=c0r0_b,
                     fusion_k=kslices[0], ffn2_k=kslices[1])
 
-    def forward_fused(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None):
+    def forward_fused(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None, out_slots=None):
         """The layer as hand-written HIP kernels plus the three big library GEMMs of the mixing: every small Linear is
         a rac_rowgemm_fwd launch whose prologue performs the residual add / split-K sum / LayerNorm / ReLU that
         precedes it in the reference (racformer_transformer.py:239-279); same arithmetic, fp32 throughout."""
         if not self.rowgemm:
             return self.forward_fused_chain(query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages)
+        self.wrote_slots = False
         meta = img_metas[0]
         time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
         qb = query_bbox.contiguous()
@@ -1095,12 +1096,15 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         c3, r2 = new(n, E), new(n, E)
         rowgemm_launch([row_gemm([row_seg(c0r0[:, :E], norm=cb[1], relu=True)], cb[3].weight, cb[3].bias, c3),
                         row_gemm([row_seg(c0r0[:, E:])], rg[2].weight, rg[2].bias, r2, relu_from=0)], n)
-        cls_score, delta = new(B, Q, self.num_classes), new(B, Q, self.code_size)
+        cls_score = out_slots[0] if out_slots is not None else new(B, Q, self.num_classes)
+        delta = new(B, Q, self.code_size)
         rowgemm_launch([row_gemm([row_seg(c3, norm=cb[4], relu=True)], cb[6].weight, cb[6].bias, cls_score),
                         row_gemm([row_seg(r2)], rg[4].weight, rg[4].bias, delta)], n)
         # refine_bbox of this layer + box table and position-encoder head of the next one, one launch
         bbox_pred, bbox_xy, next_table, next_h = layer_boundary_fused(qb, delta, meta["time_diff_safe"], self.num_ray,
-                                                                      self.pc_range, pe[0], pe[1])
+                                                                      self.pc_range, pe[0], pe[1],
+                                                                      xy_out=out_slots[1] if out_slots is not None else None)
+        self.wrote_slots = out_slots is not None
         # (the carry holds bbox_pred itself: its storage cannot be freed and handed to another tensor while the key is live)
         self._carry = ((layer + 1, bbox_pred.data_ptr(), tuple(bbox_pred.shape), bbox_pred._version), next_h, next_table, bbox_pred)
         if stages is not None:
@@ -1174,12 +1178,14 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         return x3, cls_score, bbox_pred
 
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
-                layer=0, prepared=None, stages=None):
+                layer=0, prepared=None, stages=None, out_slots=None):
+        """``out_slots``: optional (cls_score [B,Q,classes], bbox_xy [B,Q,code]) destinations -- slices of the decoder's stacked
+        outputs -- that the fused plan writes directly (no torch.stack afterwards)."""
         if prepared is None:
             prepared = self.prepare(lss_bev_feats, radar_bev_feats)
         if self.fused and attn_mask is None and query_feat.is_cuda and self.embed_dims == 256 and \
                 self.mixing.in_points <= 96:
-            return self.forward_fused(query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages)
+            return self.forward_fused(query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages, out_slots)
         meta = img_metas[0]
         time_diff, d_region = meta["time_diff"], self.d_region_list[layer]
         query_pos = self.position_encoder(query_bbox[..., :3])
@@ -1336,16 +1342,28 @@ class RaCFormerTransformerDecoder(nn.Module):
         prepared = self.decoder_layer.prepare(lss_bev_feats, radar_bev_feats)
         self.decoder_layer._carry = None
         cls_scores, bbox_preds = [], []
+        # the stacked outputs are allocated up front and every layer of the fused plan writes its slice (no torch.stack launches)
+        stacked = None
+        if query_feat.is_cuda and not torch.is_grad_enabled():
+            B, Q = query_bbox.shape[:2]
+            dl = self.decoder_layer
+            stacked = (torch.empty(self.num_layers, B, Q, dl.num_classes, device=query_feat.device, dtype=torch.float32),
+                       torch.empty(self.num_layers, B, Q, dl.code_size, device=query_feat.device, dtype=torch.float32))
         for i in range(self.num_layers):
             st = {} if stages_per_layer is not None else None
+            self.decoder_layer.wrote_slots = False
             query_feat, cls_score, bbox_pred = self.decoder_layer(
                 query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
-                layer=i, prepared=prepared, stages=st)
+                layer=i, prepared=prepared, stages=st, out_slots=(stacked[0][i], stacked[1][i]) if stacked is not None else None)
+            if stacked is not None and not self.decoder_layer.wrote_slots:
+                stacked = None                      # (a plan that does not write in place: fall back to stacking)
             if stages_per_layer is not None:
                 stages_per_layer.append(st)
             query_bbox = bbox_pred.detach()
             cls_scores.append(cls_score)
             bbox_preds.append(self.decoder_layer.last_bbox_xy)
+        if stacked is not None:
+            return stacked
         return torch.stack(cls_scores), torch.stack(bbox_preds)
 
 

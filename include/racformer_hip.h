@@ -25,6 +25,7 @@
  *   rac_bev_pool_v2_fwd/_bwd <- bev_pool_v2_ext (models/csrc/bev_pool_v2/src/bev_pool.cpp:40-111), row f2
  *   rac_add_ln_fwd    <- residual add + nn.LayerNorm (+ReLU) groups, models/racformer_transformer.py:170-258
  *   rac_layer_boundary_fwd <- rac_refine_fwd + rac_box_prep_fwd + rac_pe_head_fwd of consecutive layers, one launch
+ *   rac_head_finish_fwd <- nan_to_num of the decoder outputs + box denormalisation, models/racformer_transformer.py:58, models/racformer_head.py:124-131
  *   rac_refine_fwd    <- refine_bbox + velocity scaling + theta_d2xy_coods of the outputs
  *                        models/racformer_transformer.py:230-236,265-269,134
  *   rac_mixing_fwd    <- AdaptiveMixing.inner_forward's matmul / layer_norm / relu chain
@@ -193,6 +194,14 @@ int rac_add_ln_fwd(const float *a, int num_partials, int64_t partial_stride, int
                    const float *bias, const float *gamma, const float *beta, const float *post_residual,
                    float *out, int ld_out, int rows, int dim, float eps, int relu, void *split_out,
                    float split_scale, int split_pad, int split_layout, void *stream);
+
+/* The element-wise tail of the head over the stacked decoder outputs, one launch: cls <- nan_to_num(cls) in place
+ * (RaCFormerTransformer.forward, models/racformer_transformer.py:58) and box <- nan_to_num(xy) with the centre scaled to
+ * metres and the columns reordered to (x, y, w, l, z, h, sin, cos, vx, vy) (RaCFormer_head.forward,
+ * models/racformer_head.py:124-131).  cls: device f32 [n_cls]; xy, box: device f32 [rows][10], distinct buffers;
+ * pc_range: HOST float[6]. */
+int rac_head_finish_fwd(float *cls, int64_t n_cls, const float *xy, float *box, int64_t rows, int code_size,
+                        const float *pc_range, void *stream);
 
 /* Position-encoder head  out = relu(LayerNorm(W x + b))  for the 3-wide box input
  * (models/racformer_transformer.py:170-173); x row r at x + r*ld_x (3 values), weight [256,3], out [rows,256]. */

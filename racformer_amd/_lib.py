@@ -35,6 +35,7 @@ SIGNATURES = {
     "rac_pe_head_fwd": (_i, [_vp, _i] + [_vp] * 5 + [_i, _i, _f, _vp]),
     "rac_layer_boundary_fwd": (_i, [_vp] * 12 + [_i] * 4 + [_f, _f, _vp]),
     "rac_refine_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_f, _vp]),
+    "rac_head_finish_fwd": (_i, [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _i, _vp, _vp]),
     "rac_mixing_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _f] + [_i] * 6 + [_f, _i, _vp]),
     "rac_sasa_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
     "rac_decode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _i, _vp]),

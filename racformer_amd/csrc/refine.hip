@@ -64,6 +64,53 @@ extern "C" int rac_refine_fwd(const float *proposal, const float *delta, const f
     return rac_launch_status("rac_refine_fwd");
 }
 
+// ------------------------------------------------------------------------------------------------ head outputs
+// What RaCFormerTransformer.forward and RaCFormer_head.forward do to the stacked decoder outputs, one launch instead of five:
+//   cls  <- nan_to_num(cls)                                      (racformer_transformer.py:58)
+//   box  <- nan_to_num(xy), then centre * pc_range span + origin and the (x, y, w, l, z, h, ...) column order
+//           (racformer_head.py:124-131).  nan_to_num first, as the reference: a NaN centre becomes the range origin.
+__device__ __forceinline__ float hf_nan_to_num(float v)
+{
+    if (v != v)
+        return 0.f;
+    return fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);   // +-inf -> +-FLT_MAX (torch.nan_to_num defaults)
+}
+
+__global__ __launch_bounds__(256) void head_finish_kernel(float *__restrict__ cls, long n_cls, const float *__restrict__ xy,
+                                                          float *__restrict__ box, long rows, float x0, float y0, float z0,
+                                                          float sx, float sy, float sz)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_cls)
+        cls[i] = hf_nan_to_num(cls[i]);
+    if (i < rows) {
+#pragma clang fp contract(off)   /* multiply and add rounded separately, as the reference's two tensor operations */
+        const float *s = xy + i * 10;
+        float v[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+            v[k] = hf_nan_to_num(s[k]);
+        float *d = box + i * 10;
+        d[0] = v[0] * sx + x0; d[1] = v[1] * sy + y0; d[2] = v[3]; d[3] = v[4]; d[4] = v[2] * sz + z0;
+        d[5] = v[5]; d[6] = v[6]; d[7] = v[7]; d[8] = v[8]; d[9] = v[9];
+    }
+}
+
+extern "C" int rac_head_finish_fwd(float *cls, int64_t n_cls, const float *xy, float *box, int64_t rows, int code_size,
+                                   const float *pc_range, void *stream)
+{
+    RAC_CHECK_ARG(n_cls >= 0 && rows >= 0 && code_size == 10, "rac_head_finish_fwd: n_cls=%lld rows=%lld code_size=%d (10)",
+                  (long long)n_cls, (long long)rows, code_size);
+    const long n = n_cls > rows ? n_cls : rows;
+    if (n == 0)
+        return 0;
+    RAC_CHECK_ARG((cls || n_cls == 0) && (rows == 0 || (xy && box)) && pc_range && xy != box, "rac_head_finish_fwd: null pointer or xy aliases box");
+    hipLaunchKernelGGL(head_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cls, (long)n_cls, xy, box,
+                       (long)rows, pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1],
+                       pc_range[5] - pc_range[2]);
+    return rac_launch_status("rac_head_finish_fwd");
+}
+
 // ------------------------------------------------------------------------------------------------ layer boundary
 // One launch at the boundary between two decoder layers: refine_bbox of the finished layer (as refine_kernel) and, for
 // the boxes it produces, what the next layer computes first: the per-query box table (box_prep_kernel) and the head of the

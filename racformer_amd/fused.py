@@ -238,6 +238,20 @@ SPLIT_BIAS_PAD = 64      # extra K columns of a split image that carry the bias 
 SPLIT_SLICE = 2048       # K slice of out_proj's split-K (16 slices of the 32768-long reduction)
 
 
+def head_finish_fused(cls_scores, bbox_xy, pc_range):
+    """(nan_to_num(cls_scores) in place, boxes [..,10] = denormalised + reordered nan_to_num(bbox_xy)): the element-wise tail of
+    RaCFormerTransformer.forward / RaCFormer_head.forward in one launch (rac_head_finish_fwd)."""
+    _lib.require_gpu(cls_scores, bbox_xy, what="head_finish_fused")
+    if cls_scores.dtype != torch.float32 or bbox_xy.dtype != torch.float32 or bbox_xy.shape[-1] != 10:
+        raise RuntimeError("head_finish_fused: float32 tensors, boxes with 10 columns")
+    box = torch.empty_like(bbox_xy)
+    pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    rc = _lib.lib().rac_head_finish_fwd(_lib.ptr(cls_scores), cls_scores.numel(), _lib.ptr(bbox_xy), _lib.ptr(box), bbox_xy.numel() // 10, 10,
+                                        pc, _lib.stream_ptr())
+    _lib.check(rc, "rac_head_finish_fwd")
+    return cls_scores, box
+
+
 def layer_boundary_fused(proposal, delta, time_diff_safe, num_ray, pc_range, pe_linear, pe_norm, xy_out=None):
     """refine_fused + box_prep + pe_head for the refined boxes in one launch (rac_layer_boundary_fwd).
     -> (bbox_pred [B,Q,10], bbox_xy [B,Q,10], box_table [B,Q,8], pe_head output [B,Q,256])."""

@@ -1388,7 +1388,11 @@ class RaCFormerTransformer(nn.Module):
         self.decoder.init_weights()
 
     def forward(self, query_bbox, query_feat, mlvl_feats, lss_bev_feats, radar_bev_feats, attn_mask, img_metas,
-                stages_per_layer=None):
+                stages_per_layer=None, raw=False):
+        """``raw``: return the decoder's stacked outputs without the nan_to_num of :58 -- for a caller that applies it together
+        with its own element-wise tail (RaCFormer_head.forward: one rac_head_finish_fwd launch)."""
         cls_scores, bbox_preds = self.decoder(query_bbox, query_feat, mlvl_feats, lss_bev_feats,
                                               radar_bev_feats, attn_mask, img_metas, stages_per_layer)
+        if raw:
+            return cls_scores, bbox_preds
         return torch.nan_to_num(cls_scores), torch.nan_to_num(bbox_preds)

@@ -478,3 +478,23 @@ def test_value_proj_kernel_vs_float64(F_, H, W):
     assert torch.equal(got[0, 0], add[0])                                # the all-zero pixel: exactly the additive term
     got_b = value_proj_fused(x, w_img, alpha * SPLIT_ACT_SCALE, bias=lin.bias)
     assert ((got_b.double() - (want - add.double() + lin.bias.double())).abs() / scale).max().item() < 4 * e_fp32 + 1e-6
+
+
+def test_head_finish_kernel_matches_torch():
+    """rac_head_finish_fwd against the reference's own element-wise tail (nan_to_num of both stacked outputs,
+    racformer_transformer.py:58; centre scaling + column order, racformer_head.py:124-131), incl. NaN and +-inf entries:
+    bit-exact (the kernel rounds the multiply and the add separately, as the two tensor operations do)."""
+    from racformer_amd.fused import head_finish_fused
+    g = torch.Generator().manual_seed(5)
+    cls = torch.randn(6, 2, 37, 10, generator=g)
+    xy = torch.rand(6, 2, 37, 10, generator=g)
+    cls[0, 0, 0, 0], cls[1, 1, 3, 2], cls[2, 0, 5, 9] = float("nan"), float("inf"), float("-inf")
+    xy[0, 0, 0, 0], xy[0, 0, 1, 2], xy[3, 1, 2, 4], xy[5, 1, 36, 9] = float("nan"), float("inf"), float("-inf"), float("nan")
+    pc = syn.PC_RANGE
+    want_cls, b = torch.nan_to_num(cls), torch.nan_to_num(xy)
+    lo, span = torch.tensor(pc[0:3]), torch.tensor([pc[3] - pc[0], pc[4] - pc[1], pc[5] - pc[2]])
+    xyz = b[..., 0:3] * span + lo
+    want_box = torch.cat([xyz[..., 0:2], b[..., 3:5], xyz[..., 2:3], b[..., 5:10]], dim=-1)
+    got_cls, got_box = head_finish_fused(cls.to(DEV), xy.to(DEV), pc)
+    assert torch.equal(got_cls.cpu(), want_cls)
+    assert torch.equal(got_box.cpu(), want_box)

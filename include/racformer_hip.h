@@ -299,6 +299,12 @@ int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, flo
                    void *stream);
 int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, int N, int C, int H, int W, int c_total,
                       int c_offset, void *stream);
+/* rac_conv_pack_fwd with a per-channel bias [C] (or NULL) added before the split, for an image whose N frames come in groups
+ * of frames_per_group of which only the first live_per_group exist in src ([N / frames_per_group * live_per_group, C, H, W]):
+ * the other frames are the bias alone.  (The hidden half of the temporal-fusion input: the ConvGRU leaves the frames t >= 4 at
+ * zero, so after the resize and the last convolution they are exactly that convolution's bias, racformer_transformer.py:674-693.) */
+int rac_conv_pack_bias_fwd(const float *src, const float *bias, const float *amax, void *xs, int N, int C, int H, int W,
+                           int c_total, int c_offset, int frames_per_group, int live_per_group, void *stream);
 int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
                     float w_alpha, float *out, int N, int H, int W, int Cin, int Cout, void *stream);
 

@@ -73,10 +73,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------------ pack
-// [N][C][H][W] f32 -> channel chunks chunk0.. of xs (interior pixels only; the border stays zero)
-__global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ src, const float *__restrict__ amax,
-                                                        _Float16 *__restrict__ dst, int C, int H, int W, int chunks_total,
-                                                        int chunk0)
+// [N][C][H][W] f32 -> channel chunks chunk0.. of xs (interior pixels only; the border stays zero).
+// Optional per-channel bias, and frames in groups of T of which only the first Tv exist in src (group g, frame t < Tv: src frame
+// g*Tv + t, plus the bias; frames t >= Tv: the bias alone) -- the hidden half of the temporal-fusion input, whose frames past the
+// ConvGRU's live ones are exactly the last convolution's bias.
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ src, const float *__restrict__ bias,
+                                                        const float *__restrict__ amax, _Float16 *__restrict__ dst, int C, int H, int W,
+                                                        int chunks_total, int chunk0, int T, int Tv)
 {
     __shared__ float tile[32][129];
     const int cchunks = C >> 5;
@@ -86,9 +89,18 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict_
     const int tid = threadIdx.x;
     const float scale = cv_act_scale(*amax);
     const int w4n = W >> 2;
+    const int grp = n / T, t = n - grp * T;
+    const bool live = t < Tv;
+    const size_t ns = (size_t)grp * Tv + t;             // source frame
     for (int i = tid; i < 32 * w4n; i += 256) {
         const int ch = i / w4n, w4 = i - ch * w4n;
-        const rac_f4 v = rac_ld4(src + (((size_t)n * C + c32 * 32 + ch) * H + h) * W + w4 * 4);
+        rac_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (live)
+            v = rac_ld4(src + ((ns * C + c32 * 32 + ch) * H + h) * W + w4 * 4);
+        if (bias) {
+            const float bch = bias[c32 * 32 + ch];
+            v.x += bch; v.y += bch; v.z += bch; v.w += bch;
+        }
         tile[ch][w4 * 4 + 0] = v.x;
         tile[ch][w4 * 4 + 1] = v.y;
         tile[ch][w4 * 4 + 2] = v.z;
@@ -401,9 +413,25 @@ extern "C" int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, 
     if (N == 0)
         return 0;
     RAC_CHECK_ARG(src && amax && xs, "rac_conv_pack_fwd: null pointer");
-    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)(N * H * (C / 32))), dim3(256), 0, (hipStream_t)stream, src, amax,
-                       reinterpret_cast<_Float16 *>(xs), C, H, W, c_total / 32, c_offset / 32);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)(N * H * (C / 32))), dim3(256), 0, (hipStream_t)stream, src, (const float *)nullptr,
+                       amax, reinterpret_cast<_Float16 *>(xs), C, H, W, c_total / 32, c_offset / 32, 1, 1);
     return rac_launch_status("rac_conv_pack_fwd");
+}
+
+extern "C" int rac_conv_pack_bias_fwd(const float *src, const float *bias, const float *amax, void *xs, int N, int C, int H, int W,
+                                      int c_total, int c_offset, int frames_per_group, int live_per_group, void *stream)
+{
+    RAC_CHECK_ARG(N >= 0 && C > 0 && C % 32 == 0 && c_total % 32 == 0 && c_offset % 32 == 0 && c_offset + C <= c_total,
+                  "rac_conv_pack_bias_fwd: channels C=%d c_total=%d c_offset=%d (multiples of 32)", C, c_total, c_offset);
+    RAC_CHECK_ARG(H > 0 && W >= 4 && W <= 128 && W % 4 == 0, "rac_conv_pack_bias_fwd: W=%d (multiple of 4, <= 128)", W);
+    RAC_CHECK_ARG(frames_per_group >= 1 && live_per_group >= 0 && live_per_group <= frames_per_group && N % frames_per_group == 0,
+                  "rac_conv_pack_bias_fwd: N=%d frames in groups of %d, %d live", N, frames_per_group, live_per_group);
+    if (N == 0)
+        return 0;
+    RAC_CHECK_ARG((src || live_per_group == 0) && amax && xs, "rac_conv_pack_bias_fwd: null pointer");
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)(N * H * (C / 32))), dim3(256), 0, (hipStream_t)stream, src, bias, amax,
+                       reinterpret_cast<_Float16 *>(xs), C, H, W, c_total / 32, c_offset / 32, frames_per_group, live_per_group);
+    return rac_launch_status("rac_conv_pack_bias_fwd");
 }
 
 extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,

@@ -423,6 +423,20 @@ class ConvImage:
                                                 self.H, self.W, self.cin, int(c_offset), _lib.stream_ptr()), "rac_conv_pack_fwd")
         return self
 
+    def pack_live(self, src, bias, c_offset, frames_per_group):
+        """Channel range [c_offset, c_offset + C) from ``src`` [G * live, C, H, W] (+ per-channel ``bias``) where the image's N frames
+        come in G groups of ``frames_per_group`` and only the first ``live`` of a group exist in src; the others are the bias alone
+        (rac_conv_pack_bias_fwd)."""
+        _lib.require_gpu(src, what="ConvImage.pack_live")
+        G = self.N // frames_per_group
+        if self.N % frames_per_group != 0 or src.shape[0] % G != 0 or tuple(src.shape[2:]) != (self.H, self.W) or src.dtype != torch.float32:
+            raise RuntimeError("ConvImage.pack_live: src must be float32 [groups * live, C, H, W] matching the image")
+        _lib.check(_lib.lib().rac_conv_pack_bias_fwd(_lib.ptr(src), _lib.ptr(bias) if bias is not None else None, _lib.ptr(self.amax),
+                                                     _lib.ptr(self.xs), self.N, int(src.shape[1]), self.H, self.W, self.cin, int(c_offset),
+                                                     int(frames_per_group), int(src.shape[0] // G), _lib.stream_ptr()),
+                   "rac_conv_pack_bias_fwd")
+        return self
+
     def conv(self, ws, w_alpha, bias=None, pixel_bias=None):
         N, H, W = self.N, self.H, self.W
         out = torch.empty(N, H, W, 256, device=self.dev, dtype=torch.float32)

@@ -454,7 +454,13 @@ class RadarBEVTemporalEncoder(nn.Module):
                     gates = F.conv2d(xh[:, t], packed["gru_w"], None, padding=1)
                     gru_gate_fused(gates, xh[:, t, hd:], live[:, t], bias_map=packed["gru_bmap"],
                                    h_out2=xh[:, t + 1, hd:] if t + 1 < Tv else None)
-                hid = self.hidden_from_gru(live, T, H, W)
+                # hidden half of the image straight from the live frames: the last convolution without its bias, the bias added (and
+                # the frames past the live ones synthesised from it) by the pack kernel -- no bias-add, copy and fill launches
+                conv_up = self.upsample[1]
+                hv = F.conv2d(upsample2x_fused(live.reshape(B * Tv, hd, H // 2, W // 2)), conv_up.weight, None, conv_up.stride,
+                              conv_up.padding, conv_up.dilation, conv_up.groups)
+                img.pack_live(hv, conv_up.bias, C, T)
+                return img.conv(packed["ws"], packed["alpha"], None if pb is not None else self.temporal_fusion.bias, pb)
             else:
                 if own_down:
                     # downsample (3x3, stride 2) on the image that is being built for the fusion convolution anyway

@@ -498,3 +498,23 @@ def test_head_finish_kernel_matches_torch():
     got_cls, got_box = head_finish_fused(cls.to(DEV), xy.to(DEV), pc)
     assert torch.equal(got_cls.cpu(), want_cls)
     assert torch.equal(got_box.cpu(), want_box)
+
+
+def test_conv_pack_live_matches_explicit_assembly():
+    """rac_conv_pack_bias_fwd (bias added before the split, frames past the live ones synthesised from the bias) writes the same
+    image, bit for bit, as packing the explicitly assembled tensor: hid[:, :Tv] = src + bias, hid[:, Tv:] = bias."""
+    from racformer_amd.fused import ConvImage
+    g = torch.Generator().manual_seed(11)
+    B, T, Tv, C, H, W, Cx = 2, 4, 3, 64, 16, 16, 32
+    src = torch.randn(B * Tv, C, H, W, generator=g).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    hid = torch.empty(B, T, C, H, W, device=DEV)
+    hid[:, :Tv] = (src + bias.view(1, C, 1, 1)).view(B, Tv, C, H, W)
+    hid[:, Tv:] = bias.view(1, 1, C, 1, 1)
+    hid = hid.flatten(0, 1).contiguous()
+    a = ConvImage(B * T, H, W, Cx + C, torch.device(DEV))
+    a.begin([hid]).pack(hid, Cx)
+    want = a.xs[..., Cx // 32:, :, :].clone()
+    a.xs[..., Cx // 32:, :, :].zero_()
+    a.pack_live(src, bias, Cx, T)
+    assert torch.equal(a.xs[..., Cx // 32:, :, :], want)

@@ -96,6 +96,18 @@ def test_c_abi_argument_errors_without_gpu():
     assert rc == -1 and b"dim" in lib.rac_last_error()
     rc = lib.rac_add_ln_fwd(p8, 1, 0, 256, 1.0, None, None, p8, p8, None, p8, 256, 4, 256, 1e-5, 0, p8, 1.0, 4, 1, None)
     assert rc == -1 and b"split_layout" in lib.rac_last_error()
+    # entry points added in round 2
+    rc = lib.rac_value_proj_fwd(p16, p16, 1.0, None, None, p16, 8, 128, 16384, 256, None)
+    assert rc == -1 and b"256 -> 256" in lib.rac_last_error()
+    rc = lib.rac_value_proj_fwd(p16, p16, 1.0, None, None, p16, 8, 256, 1000, 256, None)
+    assert rc == -1 and b"multiple of 32" in lib.rac_last_error()
+    rc = lib.rac_head_finish_fwd(p8, 100, p8, p16, 10, 9, pc, None)
+    assert rc == -1 and b"code_size" in lib.rac_last_error()
+    rc = lib.rac_conv_pack_bias_fwd(p16, None, p8, p16, 8, 64, 128, 128, 320, 256, 3, 2, None)
+    assert rc == -1 and b"groups of 3" in lib.rac_last_error()
+    rc = lib.rac_generator_fwd(p16, p16, None, 1.0, p16, 2189, 900, 2189, 256, None)
+    assert rc == -1 and b"ld_out" in lib.rac_last_error()
+    assert lib.rac_value_proj_fwd(None, None, 1.0, None, None, None, 0, 256, 16384, 256, None) == 0
     # empty problems return success before touching any pointer
     assert lib.rac_msmv_fwd(None, None, 4, None, None, None, 0, 6, 900, 12, 64, 0, 0, 1, 1, None) == 0
     assert lib.rac_bev_pool_v2_fwd(None, None, None, None, None, None, None, None, 64, 0, None) == 0

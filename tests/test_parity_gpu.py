@@ -334,3 +334,19 @@ def test_layer_boundary_kernel_vs_oracle():
     assert (table[..., 6] - torch.cos(dec[..., 6])).abs().max().item() < 1e-5
     assert (table[..., 7] - torch.sin(dec[..., 6])).abs().max().item() < 1e-5
     assert (h.cpu() - want_h).abs().max().item() < 2e-5
+
+
+def test_decoder_small_batch2_vs_oracle():
+    """Two samples per forward (reduced 6-cam shapes): the B > 1 paths of the kernels -- the slot order of the image sampling
+    (quirk Q1), the frame / batch pairing of the BEV attention (quirk Q2: the keypoint chain per (t', b') instead of the hoisted
+    base points), per-batch time_diff and lidar2img -- against the oracle's restatement of the reference, literal for every
+    query.  (No reference fixture exists at B = 2: this pins the kernels to the oracle, whose B = 1 behaviour is pinned.)"""
+    from dataclasses import replace
+    cfg, seed, wseed = replace(syn.SMALL6, batch=2), 23, 24
+    sd = syn.make_state_dict(cfg, wseed)
+    qb, qf = syn.make_queries(cfg, seed)
+    ocls, obox, oviews = oracle_decoder(R, sd, qb, qf, syn.make_pyramid(cfg, seed), syn.make_bev(cfg, seed, 0),
+                                        syn.make_bev(cfg, seed, 1), syn.make_img_metas(cfg), cfg)
+    (cls, box, _), _ = run_with_reference_views(lambda force: run_decoder_gpu(cfg, seed, wseed, force), oviews, "small6 batch 2")
+    assert tuple(cls.shape[:2]) == (6, 2)
+    decoder_parity(cls, box, ocls, obox, what="small6 batch 2 vs oracle", tail_budget=None)

@@ -221,13 +221,55 @@ def _param_values(name, shape, seed):
     return n * (1.0 / np.sqrt(max(fan_in, 1)))
 
 
+def _param_values_torch_default(name, shape, seed):
+    """The DISTRIBUTIONS torch's constructors draw from (nn.Linear / nn.Conv2d: weight and bias U(+-1/sqrt(fan_in));
+    nn.MultiheadAttention: xavier-uniform in_proj, zero in_proj / out_proj bias; nn.Embedding N(0,1); nn.LayerNorm 1 / 0),
+    drawn name-keyed from PCG64 like everything else here -- the state a reference model has before its own
+    init_weights() runs (SURVEY 8d's second rig; the reference's init_weights is then applied on top by the golden
+    generator, and what it wrote is kept in tests/golden/init_params_w*.npz)."""
+    g_seed = (seed * 7919 + zlib.crc32(name.encode()) + 104729) & 0x7FFFFFFF
+    leaf = name.split(".")[-1]
+    if "embed.weight" in name:
+        return rng_normal(g_seed, tuple(shape))
+    if len(shape) == 1 and leaf == "weight":            # LayerNorm gamma
+        return np.ones(shape, np.float32)
+    if leaf == "in_proj_bias" or name.endswith("attn.out_proj.bias"):
+        return np.zeros(shape, np.float32)
+    if leaf == "bias":
+        if any(k in name for k in ("norm", "position_encoder.1", "position_encoder.4", "cls_branch.1", "cls_branch.4")):
+            return np.zeros(shape, np.float32)          # LayerNorm beta
+        fan_in = _FAN_IN_OF_BIAS.get(name.rsplit(".", 1)[0].split("decoder_layer.")[-1])
+        assert fan_in, name
+        b = 1.0 / np.sqrt(fan_in)
+        return rng_uniform(g_seed, tuple(shape), -b, b)
+    fan_in = int(np.prod(shape[1:]))
+    if leaf == "in_proj_weight":                        # xavier_uniform on the [3E, E] matrix
+        b = np.sqrt(6.0 / (shape[0] + shape[1]))
+    else:
+        b = 1.0 / np.sqrt(fan_in)
+    return rng_uniform(g_seed, tuple(shape), -b, b)
+
+
+_FAN_IN_OF_BIAS = {}
+
+
+def _note_fan_in(shapes):
+    for k, shp in shapes.items():
+        if k.endswith(".weight") and len(shp) > 1:
+            _FAN_IN_OF_BIAS[k[:-len(".weight")].split("decoder_layer.")[-1]] = int(np.prod(shp[1:]))
+
+
 @torch.no_grad()
-def fill_params(module, seed=0):
+def fill_params(module, seed=0, scheme="tamed_normal"):
     """Deterministic, name-keyed parameter fill: any two modules with the reference's
     state_dict keys get bit-identical weights without shipping
-    a 28 M-parameter checkpoint."""
-    for name, p in sorted(module.named_parameters(), key=lambda kv: kv[0]):
-        v = _param_values(name, tuple(p.shape), seed).astype(np.float32)
+    a 28 M-parameter checkpoint.  ``scheme``: "tamed_normal" (the random-everything rig) or "torch_default"
+    (the distributions of torch's constructors: the state before the reference's init_weights())."""
+    named = sorted(module.named_parameters(), key=lambda kv: kv[0])
+    _note_fan_in({k: tuple(p.shape) for k, p in named})
+    fn = _param_values if scheme == "tamed_normal" else _param_values_torch_default
+    for name, p in named:
+        v = fn(name, tuple(p.shape), seed).astype(np.float32)
         p.copy_(torch.from_numpy(v).to(p.dtype))
     return module
 
@@ -295,8 +337,10 @@ def transformer_param_shapes(cfg: RigConfig):
     return {"decoder.decoder_layer." + k: v for k, v in s.items()}
 
 
-def make_state_dict(cfg: RigConfig, seed=0):
+def make_state_dict(cfg: RigConfig, seed=0, scheme="tamed_normal"):
     """Name-keyed deterministic weights, identical to ``fill_params`` on a module with the
     same keys."""
-    return {k: torch.from_numpy(_param_values(k, shp, seed).astype(np.float32))
-            for k, shp in transformer_param_shapes(cfg).items()}
+    shapes = transformer_param_shapes(cfg)
+    _note_fan_in(shapes)
+    fn = _param_values if scheme == "tamed_normal" else _param_values_torch_default
+    return {k: torch.from_numpy(fn(k, shp, seed).astype(np.float32)) for k, shp in shapes.items()}

@@ -24,6 +24,13 @@ is written out.  What each file pins:
                        every sampling point of every layer (read at its msmv operator boundary), for flip attribution
   decoder_f8_tf.npz    teacher-forcing fixture (seed 0): every layer's (query_bbox, query_feat) INPUT and its outputs,
                        stage probes for 32 queries, selected views
+  decoder_f8_init.npz / decoder_f8_3cam_init.npz / init_params_w7.npz
+                       SURVEY 8d's second rig: weights drawn from the distributions of torch's constructors
+                       (racformer_amd.synthetic, scheme "torch_default") and then the reference's OWN init_weights()
+                       (racformer_transformer.py:218-228,292-294,355-358,470-476,577-578; bev_self_attention.py:104-112:
+                       zero offset / generator / tau weights, xavier value / output / fusion Linears) -- the low-amplification
+                       rig on which six free-running layers are compared literally: cls/box of all layers and the selected
+                       views; init_params_w7.npz holds every parameter init_weights changed (bit for bit, as data).
   decode_cases.npz     NMSFreeCoder.decode_single + RaCFormer_head.get_bboxes (nms_free_coder.py:37-88,
                        racformer_head.py:488-507): crafted ties, centres outside post_center_range, scores around 0.05
   head_small6.npz / head_f8.npz
@@ -216,11 +223,25 @@ class ViewTap:
         self.mod.msmv_sampling = self.orig
 
 
-def run_decoder(ref, cfg, seed, weight_seed, full_stages, mode="stages"):
+INIT_SEED_BASE = 90000   # torch.manual_seed(INIT_SEED_BASE + weight_seed) right before init_weights()
+
+
+def run_decoder(ref, cfg, seed, weight_seed, full_stages, mode="stages", init=False):
     """mode "stages": cls/box + stage fixtures of layers 0 and 5 (the round-1 files); "seeds": cls/box + selected views
-    only; "tf": teacher-forcing fixture (per-layer inputs / outputs, stage probes, selected views)."""
+    only; "tf": teacher-forcing fixture (per-layer inputs / outputs, stage probes, selected views).  ``init``: run the
+    reference's init_weights() on top of the seeded fill and keep every parameter it changed in the fixture."""
     tr = ref.racformer_transformer.RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
-    syn.fill_params(tr, weight_seed)
+    syn.fill_params(tr, weight_seed, scheme="torch_default" if init else "tamed_normal")
+    if init:
+        before = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+        torch.manual_seed(INIT_SEED_BASE + weight_seed)
+        tr.init_weights()
+        changed = {k: v.detach().clone() for k, v in tr.state_dict().items() if not torch.equal(v, before[k])}
+        out, dt = run_decoder_views(ref, tr, cfg, seed, weight_seed, "seeds")
+        out["init_seed"] = np.array(INIT_SEED_BASE + weight_seed)
+        out["init_params"] = np.array(f"init_params_w{weight_seed}.npz")
+        out["fill_scheme"] = np.array("torch_default")
+        return (out, changed), dt
     layer = tr.decoder.decoder_layer
     captured = {}
     if mode != "stages":
@@ -472,6 +493,19 @@ def main():
             save(f"decoder_f8_s{sd_}.npz", **out)
         out, dt = run_decoder(ref, syn.F8_3CAM, seed=1, weight_seed=1, full_stages=False, mode="seeds")
         save("decoder_f8_3cam_s1.npz", **out)
+    if want("init"):
+        # one weight seed for both f8 rigs: the parameters init_weights() touches do not depend on the number of cameras, so
+        # they are stored once (init_params_w7.npz) and both runs must produce them bit for bit
+        changed = None
+        if not args.skip_f8:
+            for name, cfg in (("decoder_f8_init.npz", syn.F8), ("decoder_f8_3cam_init.npz", syn.F8_3CAM)):
+                (out, ch2), dt = run_decoder(ref, cfg, seed=7, weight_seed=7, full_stages=False, init=True)
+                if changed is None:
+                    changed = ch2
+                    save("init_params_w7.npz", **changed)
+                assert sorted(ch2) == sorted(changed) and all(torch.equal(ch2[k], changed[k]) for k in changed)
+                print(f"  {name}: reference forward on the init_weights rig {dt:.2f}s")
+                save(name, **out)
     if not args.skip_f8 and want("tf"):
         out, dt = run_decoder(ref, syn.F8, seed=0, weight_seed=0, full_stages=False, mode="tf")
         print(f"  decoder F8 teacher-forcing fixture {dt:.2f}s")

@@ -38,6 +38,15 @@ class _BaseModule(nn.Module):
         self._is_init = False
         self.init_cfg = init_cfg
 
+    def init_weights(self):
+        """mmcv 1.6.0 BaseModule.init_weights with ``init_cfg=None`` (the only case on this path): no parameter of the
+        module itself is touched; every child that has an ``init_weights`` of its own is asked to run it."""
+        assert self.init_cfg is None, "only init_cfg=None is stubbed"
+        for m in self.children():
+            if hasattr(m, "init_weights"):
+                m.init_weights()
+        self._is_init = True
+
 
 def _identity_decorator(*dargs, **dkwargs):
     if len(dargs) == 1 and callable(dargs[0]) and not dkwargs:

@@ -17,15 +17,27 @@ What is compared, and how strictly
      with the REFERENCE'S choices imposed on the product (``view_in`` of rac_sampling4d_fwd: the only thing it changes is
      which camera those few points are sampled in).  With the discrete choices equal, the decoder is a continuous
      function of its inputs and the criterion below applies to every query: nothing is "attributed" by heuristics.
-   * the synthetic rig's random weights amplify float32 rounding 4-5x per layer.  Two fp32 CPU implementations of the
-     same arithmetic -- this repository's oracle and the reference's own files, zero differing views, fixture
-     decoder_f8_3cam_s1 -- differ by at most 1.3e-6, 7.9e-6, 2.8e-5, 6.4e-5, 6.0e-4, 1.5e-3 over the six layers (the
-     maximum sits in the un-normalised sin / cos columns): even CPU against CPU, 2 of 900 queries miss 1e-3 in the last
-     layer.  The HIP path starts from a 3x larger single-layer difference (GPU libm / FMA contraction vs the CPU's
-     SLEEF: sampling-stage median 1.8e-7 against 6e-8, tools/diag_stage_error.py), so its tail is longer.  The
-     free-running criterion therefore is: layers 0-2 literal for every query; in layers 3, 4, 5 at most
-     ``TAIL_BUDGET`` = 0.3 %, 0.6 %, 1.2 % of the queries may miss (box error > 1e-3 or argmax differing), none of them by
-     more than ``TAIL_TOL``; p50 <= 1e-4 everywhere.  Reduced configurations (30 queries) get no tail at all.
+   * the random-everything rig (every Linear N(0, 1/fan_in), offsets / mixing parameters / tau driven by the features --
+     SURVEY 8d's first rig) amplifies float32 rounding 4-5x per layer.  Two fp32 CPU implementations of the same
+     arithmetic -- this repository's oracle and the reference's own files, equal camera choices -- drift apart over the
+     six layers by what tools/measure_cpu_vs_cpu.py measures (profiles/r03_cpu_vs_cpu_drift.json, all eight f8
+     fixtures): box error at most 2.8e-6, 1.7e-5, 7.8e-5, 9.4e-5, 1.2e-3, 2.3e-3 and class-logit error at most 4.8e-6,
+     2.7e-5, 8.8e-5, 2.3e-4, 3.9e-3, 1.2e-2 in layers 0..5: even CPU against CPU, 1-2 of 900 queries miss 1e-3 in the last
+     two layers.  The criterion on THAT rig therefore is, separately for the two halves of north_star's statement:
+       - class argmax: identical for every query, except a query whose two leading REFERENCE logits are closer together
+         than ``ARGMAX_MARGIN[layer]`` = the CPU-vs-CPU logit drift measured for that layer (a tie at the resolution of the
+         arithmetic: neither implementation's argmax is "the" answer there); any other mismatch fails the test;
+       - boxes: layers 0-2 within 1e-3 for every query; in layers 3, 4, 5 at most ``TAIL_QUERIES`` = 2, 3, 5 of the 900
+         queries may miss 1e-3, none by more than ``TAIL_TOL`` = 1e-2; p50 <= 1e-4 everywhere.
+   * SURVEY 8d's SECOND rig -- weights as torch's constructors draw them, then the reference's own init_weights()
+     (zero offset / generator / tau weights, xavier value / output / fusion Linears; fixtures decoder_f8_init.npz,
+     decoder_f8_3cam_init.npz) -- is the model as the reference initialises it and does not amplify (CPU vs CPU: 2.7e-5 /
+     4.2e-5 in layer 5).  There the criterion is north_star's, LITERALLY: every query of every one of the six
+     free-running layers within 1e-3, argmax identical (subject only to the tie rule above), no tail.  Reduced
+     configurations (30 queries) and smoke() are literal too.
+   Every comparison records what it actually used (differing / imposed camera choices, box misses, argmax mismatches and
+   their margins, per layer) in ``USED``; the GPU session writes it to gpurun_out/parity_budget_used.json, and the committed
+   copy is profiles/r03_parity_budget_used.json.
 3. The NMS-free decode is positional and exact (``decode_parity``); the end-to-end detection list is matched one to one
    (``detections_parity``).
 Boxes are compared in the decoder's normalised output space (xyz / pc_range span, log sizes, sin, cos, velocity).
@@ -33,9 +45,13 @@ Boxes are compared in the decoder's normalised output space (xyz / pc_range span
 import numpy as np
 import torch
 
-TAIL_BUDGET = (0.0, 0.0, 0.0, 0.003, 0.006, 0.012)   # per layer: fraction of queries that may miss the literal criterion
-TAIL_TOL = 5e-2                                       # ... and by how much at most (box space)
-MAX_FLIPPED_POINTS = 16                               # differing camera choices per forward (of ~2.07 M points at f8)
+TAIL_QUERIES = (0, 0, 0, 2, 3, 5)                     # random-everything rig, per layer: queries (of 900) that may miss 1e-3 on the box
+TAIL_BUDGET = tuple(q / 900.0 for q in TAIL_QUERIES)  # ... as a fraction of the queries
+TAIL_TOL = 1e-2                                       # ... and by how much at most (box space)
+ARGMAX_MARGIN = (4.8e-6, 2.7e-5, 8.8e-5, 2.3e-4, 3.9e-3, 1.2e-2)   # measured CPU-vs-CPU logit drift per layer (see above)
+MAX_FLIPPED_POINTS = 8                                # differing camera choices per forward on the equalised trajectory
+                                                      # (of ~2.07 M points at f8; measured maximum + 1)
+USED = []                                             # one record per comparison: what of the allowances it actually used
 
 
 def _rows(cls, box, gcls, gbox):
@@ -75,23 +91,37 @@ def flipped_queries(views_a, views_b, num_frames, num_groups):
     return diff.any(-1).any(2)
 
 
-def decoder_parity(cls, box, gcls, gbox, box_tol=1e-3, what="", tail_budget=TAIL_BUDGET, tail_tol=TAIL_TOL):
+def decoder_parity(cls, box, gcls, gbox, box_tol=1e-3, what="", tail_budget=TAIL_BUDGET, tail_tol=TAIL_TOL,
+                   argmax_margin=ARGMAX_MARGIN):
     """cls/box [layers,B,Q,.] of a free-running decoder (camera choices equal on both sides) vs the comparand's: module
-    docstring, point 2.  ``tail_budget=None``: literal for every query of every layer."""
+    docstring, point 2.  ``tail_budget=None``: boxes literal for every query of every layer.  Class argmax is never part of
+    the tail: a mismatch passes only as a tie of the comparand's two leading logits (margin < ``argmax_margin[layer]``)."""
     rows = _rows(cls, box, gcls, gbox)
-    msgs, bad = [], []
+    gc = torch.as_tensor(gcls).double()
+    msgs, bad, used = [], [], []
     for r in rows:
-        fail = (r["eb"] > box_tol) | r["mism"]
-        n = fail.numel()
-        frac = 0.0 if tail_budget is None else tail_budget[min(r["layer"], len(tail_budget) - 1)]
-        allowed = int(frac * n)
+        l = r["layer"]
+        top2 = gc[l].reshape(-1, gc.shape[-1]).topk(2, -1).values
+        margin = top2[:, 0] - top2[:, 1]
+        lim = argmax_margin[min(l, len(argmax_margin) - 1)]
+        hard = r["mism"] & (margin >= lim)                 # argmax differs although the comparand's decision is clear
+        miss = r["eb"] > box_tol
+        n = miss.numel()
+        frac = 0.0 if tail_budget is None else tail_budget[min(l, len(tail_budget) - 1)]
+        allowed = int(round(frac * n))
         beyond = int((r["eb"] > tail_tol).sum())
-        r.update(failing=int(fail.sum()), allowed=allowed, beyond=beyond, n=n)
-        msgs.append(_fmt(what, r, f" | missing the literal criterion {r['failing']}/{n} (budget {allowed}), beyond {tail_tol:g}: {beyond}"))
-        if r["failing"] > allowed or beyond or float(r["eb"].median()) > box_tol / 10:
-            bad.append(r["layer"])
+        r.update(failing=int(miss.sum()), allowed=allowed, beyond=beyond, n=n, argmax_hard=int(hard.sum()),
+                 argmax_ties=int((r["mism"] & ~hard).sum()))
+        used.append(dict(layer=l, box_misses=r["failing"], box_budget=allowed, box_max=float(r["eb"].max()),
+                         box_p50=float(r["eb"].median()), cls_max=float(r["ec"].max()), argmax_mismatches=int(r["mism"].sum()),
+                         argmax_mismatch_margins=[float(m) for m in margin[r["mism"]]], argmax_margin_limit=lim))
+        msgs.append(_fmt(what, r, f" (of them ties below {lim:g}: {r['argmax_ties']}) | boxes over {box_tol:g}: {r['failing']}/{n} "
+                                  f"(budget {allowed}), beyond {tail_tol:g}: {beyond}"))
+        if r["failing"] > allowed or beyond or r["argmax_hard"] or float(r["eb"].median()) > box_tol / 10:
+            bad.append(l)
     msg = "\n".join(msgs)
     print(msg)
+    USED.append(dict(what=what, kind="decoder_parity", literal=tail_budget is None, layers=used, passed=not bad))
     assert not bad, f"decoder parity fails in layers {bad}:\n{msg}"
     return rows
 
@@ -230,6 +260,44 @@ def teacher_forced_layer_check(l, g, cfg, feat, cls, box, stages, views_l, tol=1
     return int(flips.sum())
 
 
+def init_rig_params(g, golden_dir):
+    """The parameters the reference's init_weights() wrote on the init_weights rig (fixture key ``init_params`` names the
+    file that holds them, bit for bit): {state_dict key: tensor}, empty for the random-everything rigs."""
+    import os
+    if "init_params" not in getattr(g, "files", g):
+        return {}
+    z = np.load(os.path.join(golden_dir, str(g["init_params"])))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def fill_scheme(g):
+    return str(g["fill_scheme"]) if "fill_scheme" in getattr(g, "files", g) else "tamed_normal"
+
+
+def load_rig_state_dict(cfg, g, golden_dir):
+    """state_dict of the rig a decoder fixture was generated on: the seeded fill, then (init rig) what init_weights() wrote."""
+    from racformer_amd import synthetic as syn
+    sd = syn.make_state_dict(cfg, int(g["weight_seed"]), scheme=fill_scheme(g))
+    for k, v in init_rig_params(g, golden_dir).items():
+        assert k in sd and sd[k].shape == v.shape, k
+        sd[k] = v.clone()
+    return sd
+
+
+def fill_rig_module(module, cfg, g, golden_dir):
+    """The same for a product (or reference) RaCFormerTransformer module, in place."""
+    from racformer_amd import synthetic as syn
+    syn.fill_params(module, int(g["weight_seed"]), scheme=fill_scheme(g))
+    over = init_rig_params(g, golden_dir)
+    if over:
+        sd = module.state_dict()
+        with torch.no_grad():
+            for k, v in over.items():
+                assert sd[k].shape == v.shape, k
+                sd[k].copy_(v)
+    return module
+
+
 def oracle_decoder(R, sd, qb, qf, pyramid, lss, radar, metas, cfg, stages=None, force_views=None):
     """The oracle's decoder forward -> (cls, box, views): views = the camera index it used for every sampling point of
     every layer ([layers,S,Q,P] uint8).  ``force_views`` [layers,S,Q,P]: impose these choices instead of its own."""
@@ -252,6 +320,7 @@ def run_with_reference_views(run, ref_views, what=""):
     bounded.  -> (outputs of the comparable run, differing points per layer on the comparable trajectory)."""
     res = run(None)
     nflip = flipped_points(res[-1], ref_views)
+    free = list(nflip)
     per_layer = int(np.prod(np.asarray(ref_views).shape[1:]))
     if sum(nflip):
         print(f"{what}: free run: differing camera choices per layer {nflip} (incl. consequences of earlier ones)")
@@ -259,5 +328,7 @@ def run_with_reference_views(run, ref_views, what=""):
         nflip = flipped_points(res[-1], ref_views)
     print(f"{what}: sampling points whose camera choice differs from the comparand's on the same trajectory, per layer: {nflip} "
           f"(of {per_layer} per layer)")
+    USED.append(dict(what=what, kind="camera_choices", free_run_differing=free, imposed=bool(sum(free)),
+                     differing_on_equalised_trajectory=nflip, points_per_layer=per_layer))
     assert sum(nflip) <= MAX_FLIPPED_POINTS, f"{what}: {nflip} differing camera choices"
     return res, nflip

@@ -6,9 +6,10 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import GOLDEN
 from oracle import restate as R
 from racformer_amd import synthetic as syn
-from parity import decoder_parity, oracle_decoder, run_with_reference_views
+from parity import decoder_parity, init_rig_params, load_rig_state_dict, oracle_decoder, run_with_reference_views
 
 
 def load(golden_dir, name):
@@ -83,8 +84,8 @@ def test_msda(golden_dir, force_torch):
 
 def _run_decoder(cfg, g, stages=None):
     """-> cls, box of the oracle with the camera choices of the fixture (its own, unless some differ: tests/parity.py)."""
-    seed, wseed = int(g["seed"]), int(g["weight_seed"])
-    sd = syn.make_state_dict(cfg, wseed)
+    seed = int(g["seed"])
+    sd = load_rig_state_dict(cfg, g, GOLDEN)
     qb, qf = syn.make_queries(cfg, seed)
 
     def run(force):
@@ -117,3 +118,35 @@ def test_decoder_f8(golden_dir, name, cfg):
     torch.set_num_threads(min(16, os.cpu_count()))
     cls, box = _run_decoder(cfg, g)
     decoder_parity(cls, box, g["cls"], g["box"], what=name)
+
+
+@pytest.mark.parametrize("name,cfg", [("decoder_f8_init.npz", syn.F8), ("decoder_f8_3cam_init.npz", syn.F8_3CAM)])
+def test_decoder_f8_init_weights_rig_literal(golden_dir, name, cfg):
+    """The oracle on SURVEY 8d's second rig (torch-constructor weights + the reference's own init_weights()): all six
+    free-running layers literal -- every query within 1e-3, argmax identical -- against the reference's CPU forward."""
+    g = load(golden_dir, name)
+    torch.set_num_threads(min(16, os.cpu_count()))
+    cls, box = _run_decoder(cfg, g)
+    rows = decoder_parity(cls, box, g["cls"], g["box"], what=name, tail_budget=None)
+    assert max(float(r["eb"].max()) for r in rows) < 2e-4        # measured 2.7e-5 / 4.2e-5: the rig does not amplify
+
+
+def test_product_init_weights_reproduces_the_references(golden_dir):
+    """RaCFormerTransformer.init_weights() of the product (the drop-in's counterpart of racformer_transformer.py:218-228,
+    292-294, 355-358, 470-476, 577-578 and bev_self_attention.py:104-112) draws from torch's generator in the reference's
+    order: under the seed the golden generator used it writes the very parameters the reference's init_weights() wrote,
+    bit for bit, and touches no other."""
+    from racformer_amd.transformer import RaCFormerTransformer
+    cfg = syn.F8
+    g = load(golden_dir, "decoder_f8_init.npz")
+    want = init_rig_params(g, golden_dir)
+    tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
+    syn.fill_params(tr, int(g["weight_seed"]), scheme="torch_default")
+    before = {k: v.detach().clone() for k, v in tr.state_dict().items()}
+    torch.manual_seed(int(g["init_seed"]))
+    tr.init_weights()
+    after = tr.state_dict()
+    changed = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    assert changed == sorted(want), (set(changed) ^ set(want))
+    for k in changed:
+        assert torch.equal(after[k], want[k]), k

@@ -10,8 +10,8 @@ import pytest
 import torch
 
 from oracle import restate as R
-from parity import (decode_parity, decoder_parity, detections_parity, flipped_points, head_boxes_normalised, kept_rows,
-                    oracle_decoder, run_with_reference_views, teacher_forced_layer_check)
+from parity import (decode_parity, decoder_parity, detections_parity, fill_rig_module, flipped_points, head_boxes_normalised,
+                    kept_rows, oracle_decoder, run_with_reference_views, teacher_forced_layer_check)
 from racformer_amd import synthetic as syn
 from racformer_amd.head import RaCFormer_head
 from racformer_amd.transformer import RaCFormerTransformer, regroup_pyramid
@@ -30,10 +30,15 @@ def gpu_views(layer, cfg):
     return torch.stack([R.views_of(l.cpu(), cfg.num_cams) for l in layer.sampling.capture_loc])
 
 
-def run_decoder_gpu(cfg, seed, wseed, force_views=None, **layer_flags):
-    """-> (cls, box, views): one forward of the product decoder; ``force_views`` [layers,S,Q,P] imposes the camera choices."""
+def run_decoder_gpu(cfg, seed, wseed, force_views=None, rig=None, **layer_flags):
+    """-> (cls, box, views): one forward of the product decoder; ``force_views`` [layers,S,Q,P] imposes the camera choices.
+    ``rig`` = (fixture, golden_dir): the weights of the rig that fixture was generated on (init_weights rig) instead of the
+    seeded random-everything fill."""
     tr = RaCFormerTransformer(**cfg.transformer_kwargs()).eval()
-    syn.fill_params(tr, wseed)
+    if rig is not None:
+        fill_rig_module(tr, cfg, *rig)
+    else:
+        syn.fill_params(tr, wseed)
     layer = tr.decoder.decoder_layer
     for k, v in layer_flags.items():
         assert hasattr(layer, k), k
@@ -62,6 +67,18 @@ def test_decoder_f8_vs_reference_all_seeds(golden_dir, name, cfg):
     seed, wseed = int(g["seed"]), int(g["weight_seed"])
     (cls, box, _), _ = run_with_reference_views(lambda force: run_decoder_gpu(cfg, seed, wseed, force), g["views"], name)
     decoder_parity(cls, box, g["cls"], g["box"], what=name)
+
+
+@pytest.mark.parametrize("name,cfg", [("decoder_f8_init.npz", syn.F8), ("decoder_f8_3cam_init.npz", syn.F8_3CAM)])
+def test_decoder_f8_init_weights_rig_literal(golden_dir, name, cfg):
+    """SURVEY 8d's second rig at full f8 shapes: the model as the reference initialises it (torch's constructor distributions,
+    then the reference's own init_weights(); what that wrote is in init_params_w7.npz).  north_star's criterion, literally:
+    every query of all six free-running layers within 1e-3 on the box, class argmax identical -- no tail budget."""
+    g = np.load(os.path.join(golden_dir, name))
+    seed, wseed = int(g["seed"]), int(g["weight_seed"])
+    (cls, box, _), _ = run_with_reference_views(lambda force: run_decoder_gpu(cfg, seed, wseed, force, rig=(g, golden_dir)),
+                                                g["views"], name)
+    decoder_parity(cls, box, g["cls"], g["box"], what=name, tail_budget=None)
 
 
 @pytest.mark.parametrize("name,cfg", [("decoder_small.npz", syn.SMALL), ("decoder_small6.npz", syn.SMALL6)])

@@ -227,6 +227,11 @@ def main():
     ap.add_argument("--no-stress", action="store_true", help="skip the uniform-stress timing of the operator kernels")
     ap.add_argument("--pregrouped", action="store_true",
                     help="feed the pyramid already in the sampling layout (producer-side layout, row f2): no regroup")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="time the eager plan (one Python-issued launch per kernel) instead of the captured HIP graph")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the RCCL process group and issue the all-gather even in a world of one rank "
+                         "(single-GPU rehearsal of the N > 1 path)")
     ap.add_argument("--blas", default="", help="torch.backends.cuda.preferred_blas_library override (experiment)")
     ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -243,8 +248,17 @@ def main():
         return plumbing_only(args, rank, world)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = world > 1 or args.force_collective
+    if use_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", init_method="env://", device_id=device)  # RCCL on ROCm
     _lib.lib()  # fail loudly if the HIP library is missing
     if args.blas:
@@ -262,37 +276,68 @@ def main():
         pyramid = regroup_pyramid(pyramid, cfg.num_cams, 4, fdt)
         head.transformer.decoder.pregrouped = True
 
-    def step():
+    def eager_step():
         with torch.no_grad():
             fresh = [dict(m) for m in metas]                # new sample -> metas are staged (H2D) again
             preds = head(list(pyramid), lss, radar, fresh)
             det = head.get_detections_fixed(preds)          # [1,300,11]
-            return dp.all_gather_detections(det)            # [world,1,300,11]
+            return dp.all_gather_detections(det, force_collective=args.force_collective)   # [world,1,300,11]
+
+    captured = None
+    if not args.no_graph:
+        # the whole step (regroup + prologue + 6 layers + decode) as ONE HIP-graph submission; per step the host stages the
+        # sample's metas (timestamps -> time_diff, lidar2img: the float64 host arithmetic of racformer_transformer.py:99-109)
+        # in front of the replay and issues the all-gather behind it
+        from racformer_amd.graph import CapturedStep
+        captured = CapturedStep(head, pyramid, lss, radar, metas)
+
+    def step():
+        if captured is None:
+            return eager_step()
+        _, det = captured.replay(img_metas=metas)
+        return dp.all_gather_detections(det, force_collective=args.force_collective)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
-    # inside the timed region only the dominant kernel is bracketed with HIP events (each pair costs a 5-10 us bubble);
-    # the other instrumented launches are timed in three extra, untimed steps below
-    _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "msmv_fwd"))
+    # Eager plan: inside the timed region only the dominant kernel is bracketed with HIP events (each pair costs a 5-10 us
+    # bubble); the other instrumented launches are timed in three extra, untimed steps below.  Captured plan: a graph holds
+    # no event brackets, so the timed region is K replays and the dominant kernel is bracketed in K eager steps of the same
+    # work right behind it (same kernels, same inputs, same stream).
+    if captured is None:
+        _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "msmv_fwd"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     host_elapsed = time.perf_counter() - t0     # the host has enqueued every step (it runs ahead of the GPU unless it is the limiter)
     fence()
     elapsed = time.perf_counter() - t0
+    if captured is not None:
+        _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "msmv_fwd"))
+        for _ in range(args.steps):
+            eager_step()
+        fence()
     timer, _lib.timer = _lib.timer, _lib.KernelTimer()
     for _ in range(3):
-        step()
+        eager_step()
     fence()
     aux, _lib.timer = _lib.timer, None
     per_rank_ms = [1e3 * elapsed / args.steps]
+    collective = None
+    if use_pg:
+        # the gathered block of this rank's slot is its local block, bit for bit
+        with torch.no_grad():
+            local = head.get_detections_fixed(head(list(pyramid), lss, radar, [dict(m) for m in metas]))
+            gathered = dp.all_gather_detections(local, force_collective=args.force_collective)
+        torch.cuda.synchronize()
+        collective = {"backend": dist.get_backend(), "world": world, "forced_at_world_1": bool(args.force_collective and world == 1),
+                      "gathered_shape": list(gathered.shape), "own_slot_equals_local": bool(torch.equal(gathered[rank], local))}
     if world > 1:
         mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
@@ -309,7 +354,7 @@ def main():
     cap = _lib.KernelTimer()
     cap.capture_inputs, cap.captured = True, []
     _lib.timer = cap
-    step()
+    eager_step()
     torch.cuda.synchronize()
     _lib.timer = None
     elt = 4 if fdt == torch.float32 else 2
@@ -361,7 +406,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "per_rank_ms_per_step": per_rank_ms,
         # host-side time to enqueue one step (Python + launches, rank 0): close to ms_per_step means the host is the limiter
         "host_enqueue_ms_per_step": 1e3 * host_elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "submission": "eager: one launch per kernel from Python" if captured is None else
+                      "HIP graph: the step's kernels captured once (racformer_amd/graph.py), one replay per step; metas staged in "
+                      "front of it, all-gather behind it",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "collective": collective,
         "dtype": "f32" if fdt == torch.float32 else "bf16-features/f32-math", "data": "synthetic",
         "arithmetic_note": "fp32 storage and fp32-accurate results throughout; the largest contractions run on the 16-bit "
                            "matrix cores as split-precision products (operands = sums of f16/bf16 terms, fp32 accumulate, "
@@ -381,6 +429,9 @@ def main():
                      "hbm_frac_measured": (traffic / (msmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and msmv_ms else None,
                      "limiter": "L1/L2 gather-request rate (HBM-side traffic is below the algorithmic bytes)",
                      "avg_launch_ms": msmv_ms, "launches_per_step": len(cap.captured),
+                     "timed_in": "HIP events on the launch stream inside the timed region" if captured is None else
+                                 f"HIP events on the launch stream over {args.steps} eager steps of the same work right behind the "
+                                 "timed region (a captured graph holds no event brackets)",
                      "algorithmic_bytes_per_launch": b_alg, "algorithmic_bytes_all_in_range": b_alg_closed,
                      "in_range_fraction_per_layer": in_frac,
                      "bev_sampling": {"avg_launch_ms": msda_ms, "streams_per_launch": bev_streams, "algorithmic_bytes_per_launch": bev_alg,
@@ -392,6 +443,33 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_stress:
         result["roofline_stress"] = stress_block(cfg, device)
+
+    if rank == 0 and world == 1 and not args.pregrouped and captured is not None:
+        # SECOND line, never the headline (row f2): the same step when the producer hands over the pyramid already in the
+        # sampling layout [B*T*G, N, H, W, C] (racformer_amd/fpn_writer.py writes it from the neck's last convolution), i.e.
+        # without the 1.47 GB regroup of racformer_transformer.py:112-124
+        from racformer_amd.graph import CapturedStep
+        from racformer_amd.transformer import regroup_pyramid
+        dec = head.transformer.decoder
+        grouped = regroup_pyramid(pyramid, cfg.num_cams, 4, fdt)
+        dec.pregrouped = True
+        try:
+            cap2 = CapturedStep(head, grouped, lss, radar, metas)
+            for _ in range(args.warmup):
+                cap2.replay(img_metas=metas)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                cap2.replay(img_metas=metas)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            result["pregrouped_producer_layout"] = {
+                "value": args.steps / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / args.steps,
+                "note": "secondary figure: pyramid handed over as [B*T*G,N,H,W,C] (producer-side layout, SURVEY 8 row f2), no "
+                        "regroup in the step; the headline `value` times the reference layout WITH the regroup"}
+            del cap2
+        finally:
+            dec.pregrouped = False
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -443,7 +521,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_pg:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAC_ABI_VERSION 3
+#define RAC_ABI_VERSION 4
 #define RAC_MAX_LEVELS 8
 #define RAC_MAX_POINTS 128 /* same limit as the reference, msmv_sampling_forward.cu:21 */
 
@@ -256,7 +256,7 @@ int rac_gemm_split_pack_fwd(const float *weight, void *image, int N, int K, floa
  *   partials[s][m][n] = sum_{k in slice s} Z[m][k] * W[n][k]        (unscaled: the consumer applies both powers of two)
  *   z_image : device f16 line image [M][K/32][hi 32 | lo 32]   (rac_mixing_fwd's out_split)
  *   w_image : device f16 line image [N][K/32][hi 32 | lo 32]   (rac_gemm_split_pack_fwd)
- *   partials: device f32 [slices][M][N];  K % (32 * slices) == 0.  rac_add_ln_fwd sums the slices. */
+ *   partials: device f32 [slices][M][N];  K % (32 * slices) == 0 and N % 4 == 0 (16-byte stores).  rac_add_ln_fwd sums the slices. */
 int rac_outproj_fwd(const void *z_image, const void *w_image, float *partials, int M, int N, int K, int slices, void *stream);
 
 /* AdaptiveMixing.parameter_generator (nn.Linear(256 -> groups*(64*64 + 128*in_points)), models/racformer_transformer.py:565,589)
@@ -290,11 +290,12 @@ int rac_value_proj_fwd(const float *x, const void *w_image, float w_alpha, const
  *   rac_conv_pack_fwd src [N,C,H,W] f32 -> channel range [c_offset, c_offset+C) of the kernel's activation image
  *                     xs = f16 [N][H+2][W+2][c_total/32][2][32] (per pixel and 32-channel chunk: hi, then lo, of
  *                     v * 2^e; e from *amax).  Only interior pixels are written: the caller zeroes xs once (border =
- *                     the convolution's zero padding).  W % 4 == 0, W <= 128, channel counts multiples of 32.
+ *                     the convolution's zero padding).  Any H, W (16-byte loads when W % 4 == 0); channel counts multiples of 32.
  *   rac_conv3x3_fwd   out [N,H,W,256] f32 (channel-last) = conv3x3(xs) * w_alpha / 2^e + bias[c] (or + pixel_bias[h*W+w][c]
  *                     if pixel_bias != NULL: a per-pixel additive map shared by the N images), with
  *                     ws = f16 [9 taps (ky*3+kx)][Cin/32][256][2][32] holding hi / lo of weight[co][ci][ky][kx] / w_alpha
- *                     (w_alpha a power of two chosen by the packer).  H*W must be a multiple of 256. */
+ *                     (w_alpha a power of two chosen by the packer).  Any H*W (tiles of 256 pixels, the last one of an image
+ *                     ragged); a pixel_bias map needs H*W to be a multiple of 256. */
 int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, int num, float floor_value, float *amax_out,
                    void *stream);
 int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, int N, int C, int H, int W, int c_total,
@@ -307,6 +308,18 @@ int rac_conv_pack_bias_fwd(const float *src, const float *bias, const float *ama
                            int c_total, int c_offset, int frames_per_group, int live_per_group, void *stream);
 int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
                     float w_alpha, float *out, int N, int H, int W, int Cin, int Cout, void *stream);
+
+/* Producer-side pyramid layout: the last stage of the image neck -- the per-level 3x3 / pad 1 /
+ * Cin -> 256 output convolution of the FPN (mmdet 2.28.2 FPN.fpn_convs[i], the same structure as the in-tree CustomFPN,
+ * models/necks/fpn.py:109-132,180) -- writing the layout the decoder samples from directly, so that the reshape / permute copy
+ * of models/racformer_transformer.py:112-124 (1.47 GB of traffic per sample at f8) never runs:
+ *   xs / ws / amax / w_alpha : as for rac_conv3x3_fwd (activation image of the laterals [num_images, Cin, H, W], image index
+ *                              (b*T + t) * num_cams + cam; packed weights [9][Cin/32][256][2][32])
+ *   out : device f32 [num_images / num_cams * 4][num_cams][H][W][64]: slot (b*T + t) * 4 + g holds output channels g*64..g*64+63
+ *         of the num_cams images of (b, t), channel-last -- the `feats` operand of rac_sampling4d_fwd / rac_msmv_fwd.
+ * bias: device f32 [256] or NULL.  num_images % num_cams == 0; any H, W. */
+int rac_fpn_conv_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
+                     int num_images, int H, int W, int Cin, int num_cams, void *stream);
 
 /* Element-wise pieces of RadarBEVTemporalEncoder (models/racformer_transformer.py:618-720).
  *   rac_gru_gate_fwd   ConvGRUCell update after the gates convolution (:705-720): gates [B,3C,H,W] (z | r | cand),

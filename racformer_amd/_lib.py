@@ -50,6 +50,7 @@ SIGNATURES = {
     "rac_conv_pack_fwd": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_vp]),
     "rac_conv_pack_bias_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "rac_conv3x3_fwd": (_i, [_vp] * 5 + [_f, _vp] + [_i] * 5 + [_vp]),
+    "rac_fpn_conv_fwd": (_i, [_vp] * 4 + [_f, _vp] + [_i] * 5 + [_vp]),
     "rac_conv3x3s2_fwd": (_i, [_vp] * 4 + [_f, _vp] + [_i] * 7 + [_vp]),
     "rac_bev_sampling_fwd": (_i, [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
     "rac_bev_sampling_multi_fwd": (_i, [_i] + [_vp] * 9 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),

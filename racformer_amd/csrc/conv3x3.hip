@@ -81,33 +81,46 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict_
                                                         const float *__restrict__ amax, _Float16 *__restrict__ dst, int C, int H, int W,
                                                         int chunks_total, int chunk0, int T, int Tv)
 {
+    // one block = 32 channels x one image row x up to 128 columns (wider rows -- the FPN's 176 -- take several blocks)
     __shared__ float tile[32][129];
-    const int cchunks = C >> 5;
-    const int c32 = blockIdx.x % cchunks;
-    const int h = (blockIdx.x / cchunks) % H;
-    const int n = blockIdx.x / (cchunks * H);
+    const int cchunks = C >> 5, wpieces = (W + 127) >> 7;
+    const int wp = blockIdx.x % wpieces;
+    const int c32 = (blockIdx.x / wpieces) % cchunks;
+    const int h = (blockIdx.x / (wpieces * cchunks)) % H;
+    const int n = blockIdx.x / (wpieces * cchunks * H);
     const int tid = threadIdx.x;
     const float scale = cv_act_scale(*amax);
-    const int w4n = W >> 2;
+    const int w0 = wp << 7, wlen = min(128, W - w0);
     const int grp = n / T, t = n - grp * T;
     const bool live = t < Tv;
     const size_t ns = (size_t)grp * Tv + t;             // source frame
-    for (int i = tid; i < 32 * w4n; i += 256) {
-        const int ch = i / w4n, w4 = i - ch * w4n;
-        rac_f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (live)
-            v = rac_ld4(src + ((ns * C + c32 * 32 + ch) * H + h) * W + w4 * 4);
-        if (bias) {
-            const float bch = bias[c32 * 32 + ch];
-            v.x += bch; v.y += bch; v.z += bch; v.w += bch;
+    if ((W & 3) == 0) {
+        const int w4n = wlen >> 2;
+        for (int i = tid; i < 32 * w4n; i += 256) {
+            const int ch = i / w4n, w4 = i - ch * w4n;
+            rac_f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (live)
+                v = rac_ld4(src + ((ns * C + c32 * 32 + ch) * H + h) * W + w0 + w4 * 4);
+            if (bias) {
+                const float bch = bias[c32 * 32 + ch];
+                v.x += bch; v.y += bch; v.z += bch; v.w += bch;
+            }
+            tile[ch][w4 * 4 + 0] = v.x;
+            tile[ch][w4 * 4 + 1] = v.y;
+            tile[ch][w4 * 4 + 2] = v.z;
+            tile[ch][w4 * 4 + 3] = v.w;
         }
-        tile[ch][w4 * 4 + 0] = v.x;
-        tile[ch][w4 * 4 + 1] = v.y;
-        tile[ch][w4 * 4 + 2] = v.z;
-        tile[ch][w4 * 4 + 3] = v.w;
+    } else {
+        for (int i = tid; i < 32 * wlen; i += 256) {     // rows are not 16-byte aligned: scalar loads (coarse FPN levels only)
+            const int ch = i / wlen, w = i - ch * wlen;
+            float v = live ? src[((ns * C + c32 * 32 + ch) * H + h) * W + w0 + w] : 0.f;
+            if (bias)
+                v += bias[c32 * 32 + ch];
+            tile[ch][w] = v;
+        }
     }
     __syncthreads();
-    for (int i = tid; i < W * 8; i += 256) {
+    for (int i = tid; i < wlen * 8; i += 256) {
         const int w = i >> 3, s = i & 7, c0 = (s & 3) * 8;
         cv_h8 o;
 #pragma unroll
@@ -116,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict_
             const _Float16 hi = (_Float16)v;
             o[j] = s < 4 ? hi : (_Float16)(v - (float)hi);
         }
-        const size_t pix = ((size_t)n * (H + 2) + h + 1) * (W + 2) + w + 1;
+        const size_t pix = ((size_t)n * (H + 2) + h + 1) * (W + 2) + w0 + w + 1;
         *reinterpret_cast<cv_h8 *>(dst + (pix * chunks_total + chunk0 + c32) * 64 + s * 8) = o;
     }
 }
@@ -131,23 +144,30 @@ struct ConvArgs {
     float *out;
     int N, H, W, chunks;
     float w_alpha;
+    int cams;                 // GROUPED output only: images per (batch, frame)
 };
 
+// GROUPED = false: out [N][H][W][256] channel-last.  GROUPED = true: the decoder's sampling layout of a feature-pyramid
+// level, [N / cams * 4][cams][H][W][64] -- image n = (b*T + t) * cams + cam, output channel co = g * 64 + c lands in slot
+// (b*T + t) * 4 + g (models/racformer_transformer.py:112-124: what the reference builds with a reshape / permute copy of
+// the FPN's output; here the FPN's last convolution writes it).
+template <bool GROUPED>
 __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
 {
     extern __shared__ uint4 lds4[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wm = wave >> 2, wn = wave & 3;
     const int H = a.H, W = a.W, Wp = W + 2, chunks = a.chunks;
-    const int tiles_per_img = (H * W) / CV_TM;
-    const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
+    const int HW = H * W;
+    const int tiles_per_img = (HW + CV_TM - 1) / CV_TM;    // the last tile of an image may be ragged: its rows past the image
+    const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;   // re-read the last pixel and are not stored
     const int KS = 9 * chunks;
     const size_t pix_stride = (size_t)chunks * 8;   // uint4 per pixel
 
     // staging role: 16-byte slot (tid & 7) of rows (tid >> 3) + 64 j of both the A and the B tile
     auto row_base = [&](int j) -> size_t {
         const int r = (tid >> 3) + 64 * j;
-        const int gp = tile * CV_TM + r, h = gp / W, w = gp - h * W;
+        const int gp = min(tile * CV_TM + r, HW - 1), h = gp / W, w = gp - h * W;
         return (((size_t)n * (H + 2) + h) * Wp + w) * pix_stride + (tid & 7);
     };
     auto row_slot = [&](int j) -> int {
@@ -232,7 +252,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
 
     // epilogue: undo the two power-of-two scalings, add the bias (per channel, or per pixel and channel), channel-last store
     const float unscale = a.w_alpha / cv_act_scale(*a.amax);
-    float *obase = a.out + ((size_t)n * H * W + (size_t)tile * CV_TM) * CV_COUT;
+    const int prows = min(CV_TM, HW - tile * CV_TM);       // valid pixels of this tile
+    if (GROUPED) {
+        // wave column wn IS the group (64 channels each): slot = (n / cams) * 4 + wn, view = n % cams
+        const int bt = n / a.cams, cam = n - bt * a.cams;
+        float *obase = a.out + ((((size_t)bt * 4 + wn) * a.cams + cam) * HW + (size_t)tile * CV_TM) * 64;
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            const int c = 16 * nn + li;
+            const float bv = a.bias ? a.bias[64 * wn + c] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = 128 * wm + 16 * m + 4 * lk + r;
+                    if (p < prows)
+                        obase[(size_t)p * 64 + c] = acc[m][nn][r] * unscale + bv;
+                }
+        }
+        return;
+    }
+    float *obase = a.out + ((size_t)n * HW + (size_t)tile * CV_TM) * CV_COUT;
     const float *pbase = a.pixel_bias ? a.pixel_bias + (size_t)tile * CV_TM * CV_COUT : nullptr;
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
@@ -243,8 +283,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int p = 128 * wm + 16 * m + 4 * lk + r;
-                const float pb = pbase ? pbase[(size_t)p * CV_COUT + col] : bv;
-                obase[(size_t)p * CV_COUT + col] = acc[m][nn][r] * unscale + pb;
+                if (p < prows) {
+                    const float pb = pbase ? pbase[(size_t)p * CV_COUT + col] : bv;
+                    obase[(size_t)p * CV_COUT + col] = acc[m][nn][r] * unscale + pb;
+                }
             }
     }
 }
@@ -409,11 +451,11 @@ extern "C" int rac_conv_pack_fwd(const float *src, const float *amax, void *xs, 
 {
     RAC_CHECK_ARG(N >= 0 && C > 0 && C % 32 == 0 && c_total % 32 == 0 && c_offset % 32 == 0 && c_offset + C <= c_total,
                   "rac_conv_pack_fwd: channels C=%d c_total=%d c_offset=%d (multiples of 32)", C, c_total, c_offset);
-    RAC_CHECK_ARG(H > 0 && W >= 4 && W <= 128 && W % 4 == 0, "rac_conv_pack_fwd: W=%d (multiple of 4, <= 128)", W);
+    RAC_CHECK_ARG(H > 0 && W >= 1 && (long)N * H * (C / 32) * ((W + 127) / 128) < (1l << 31), "rac_conv_pack_fwd: H=%d W=%d", H, W);
     if (N == 0)
         return 0;
     RAC_CHECK_ARG(src && amax && xs, "rac_conv_pack_fwd: null pointer");
-    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)(N * H * (C / 32))), dim3(256), 0, (hipStream_t)stream, src, (const float *)nullptr,
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)(N * H * (C / 32) * ((W + 127) / 128))), dim3(256), 0, (hipStream_t)stream, src, (const float *)nullptr,
                        amax, reinterpret_cast<_Float16 *>(xs), C, H, W, c_total / 32, c_offset / 32, 1, 1);
     return rac_launch_status("rac_conv_pack_fwd");
 }
@@ -423,13 +465,13 @@ extern "C" int rac_conv_pack_bias_fwd(const float *src, const float *bias, const
 {
     RAC_CHECK_ARG(N >= 0 && C > 0 && C % 32 == 0 && c_total % 32 == 0 && c_offset % 32 == 0 && c_offset + C <= c_total,
                   "rac_conv_pack_bias_fwd: channels C=%d c_total=%d c_offset=%d (multiples of 32)", C, c_total, c_offset);
-    RAC_CHECK_ARG(H > 0 && W >= 4 && W <= 128 && W % 4 == 0, "rac_conv_pack_bias_fwd: W=%d (multiple of 4, <= 128)", W);
+    RAC_CHECK_ARG(H > 0 && W >= 1 && (long)N * H * (C / 32) * ((W + 127) / 128) < (1l << 31), "rac_conv_pack_bias_fwd: H=%d W=%d", H, W);
     RAC_CHECK_ARG(frames_per_group >= 1 && live_per_group >= 0 && live_per_group <= frames_per_group && N % frames_per_group == 0,
                   "rac_conv_pack_bias_fwd: N=%d frames in groups of %d, %d live", N, frames_per_group, live_per_group);
     if (N == 0)
         return 0;
     RAC_CHECK_ARG((src || live_per_group == 0) && amax && xs, "rac_conv_pack_bias_fwd: null pointer");
-    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)(N * H * (C / 32))), dim3(256), 0, (hipStream_t)stream, src, bias, amax,
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)(N * H * (C / 32) * ((W + 127) / 128))), dim3(256), 0, (hipStream_t)stream, src, bias, amax,
                        reinterpret_cast<_Float16 *>(xs), C, H, W, c_total / 32, c_offset / 32, frames_per_group, live_per_group);
     return rac_launch_status("rac_conv_pack_bias_fwd");
 }
@@ -439,7 +481,8 @@ extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias
 {
     RAC_CHECK_ARG(Cout == CV_COUT, "rac_conv3x3_fwd: built for %d output channels (got %d)", CV_COUT, Cout);
     RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "rac_conv3x3_fwd: Cin=%d (multiple of 32)", Cin);
-    RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0 && (H * W) % CV_TM == 0, "rac_conv3x3_fwd: H*W=%d must be a multiple of %d", H * W, CV_TM);
+    RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0, "rac_conv3x3_fwd: N=%d H=%d W=%d", N, H, W);
+    RAC_CHECK_ARG(!pixel_bias || (H * W) % CV_TM == 0, "rac_conv3x3_fwd: a pixel_bias map needs H*W=%d to be a multiple of %d", H * W, CV_TM);
     if (N == 0)
         return 0;
     RAC_CHECK_ARG(xs && ws && amax && out, "rac_conv3x3_fwd: null pointer");
@@ -447,15 +490,35 @@ extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias
     a.xs = reinterpret_cast<const uint4 *>(xs);
     a.ws = reinterpret_cast<const uint4 *>(ws);
     a.bias = bias; a.pixel_bias = pixel_bias; a.amax = amax; a.out = out;
-    a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha;
+    a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = 1;
     const int lds = 2 * CV_STAGE_U4 * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(conv3x3_f16x3_kernel, dim3((unsigned)(N * (H * W / CV_TM))), dim3(512), lds, (hipStream_t)stream, a);
+    if (rac_first_use_on_device(RAC_ATTR_CONV3X3))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(conv3x3_f16x3_kernel<false>, dim3((unsigned)(N * ((H * W + CV_TM - 1) / CV_TM))), dim3(512), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_conv3x3_fwd");
+}
+
+extern "C" int rac_fpn_conv_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
+                                int num_images, int H, int W, int Cin, int num_cams, void *stream)
+{
+    RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "rac_fpn_conv_fwd: Cin=%d (multiple of 32)", Cin);
+    RAC_CHECK_ARG(num_images >= 0 && H > 0 && W > 0 && num_cams >= 1 && num_images % num_cams == 0,
+                  "rac_fpn_conv_fwd: %d images of %dx%d from %d cameras (the images must be whole (batch, frame) groups)", num_images, H, W,
+                  num_cams);
+    if (num_images == 0)
+        return 0;
+    RAC_CHECK_ARG(xs && ws && amax && out, "rac_fpn_conv_fwd: null pointer");
+    ConvArgs a;
+    a.xs = reinterpret_cast<const uint4 *>(xs);
+    a.ws = reinterpret_cast<const uint4 *>(ws);
+    a.bias = bias; a.pixel_bias = nullptr; a.amax = amax; a.out = out;
+    a.N = num_images; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = num_cams;
+    const int lds = 2 * CV_STAGE_U4 * 16;
+    if (rac_first_use_on_device(RAC_ATTR_FPN_CONV))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(conv3x3_f16x3_kernel<true>, dim3((unsigned)(num_images * ((H * W + CV_TM - 1) / CV_TM))), dim3(512), lds,
+                       (hipStream_t)stream, a);
+    return rac_launch_status("rac_fpn_conv_fwd");
 }
 
 extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha,
@@ -476,11 +539,8 @@ extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bi
     a.bias = bias; a.amax = amax; a.out = out;
     a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.chunks_total = Cin_image / 32; a.out_ctotal = out_channels_total; a.w_alpha = w_alpha;
     const int lds = 2 * (S2_TM * 8 + 512) * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (rac_first_use_on_device(RAC_ATTR_CONV3X3S2))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3s2_c64_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(conv3x3s2_c64_f16x3_kernel, dim3((unsigned)(N * ((H / 2) * (W / 2) / S2_TM))), dim3(S2_THREADS), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_conv3x3s2_fwd");
 }

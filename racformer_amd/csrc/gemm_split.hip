@@ -263,6 +263,7 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
     const int m0 = blockIdx.y * g.rows_per_wg;            // this workgroup's rows m0 .. m0 + mrows - 1
     const int mrows = min(g.rows_per_wg, g.M - m0);
     const int nstages = (mrows + GW_ROWS - 1) / GW_ROWS;
+    const bool full_n = n0 + 32 <= g.N;                   // every feature of this wave is stored (wave-uniform)
 
     // ---- X loader role: piece = one row (1 KB); wave w moves rows w, w+8, w+16, w+24 of every stage.  LDS slot `lane` of
     // the row receives the row's 16-byte chunk lane ^ (row & 15) (source-side swizzle, see the fragment reads)
@@ -386,13 +387,26 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
         }
         // stage st+1 must have landed before anyone reads it.  Issue order of this wave's vector-memory operations:
         //   ... P(st+1) S(st-2) | P(st+2) S(st-1) | P(st+3) S(st)      (P: 4 pieces, S: up to 4 stores; P before S either way)
-        // so at most 20 younger operations may remain outstanding behind P(st+1); towards the end fewer pieces follow.
-        if (st + 3 < nstages)
-            asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-        else if (st + 2 < nstages)
-            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        // A wave whose 32 features and whose stage rows are all inside the output issues exactly 4 stores per stage: at most
+        // 20 younger operations may then remain outstanding behind P(st+1) (fewer pieces follow towards the end).  Any other
+        // wave (features at or beyond N in the last feature block, a partial last row stage: the compiler branches around
+        // stores no lane takes) issues an unknown number of stores: it may only leave the pieces themselves outstanding.
+        const bool four_stores = full_n && (st + 1) * GW_ROWS <= mrows;     // wave-uniform
+        if (four_stores) {
+            if (st + 3 < nstages)
+                asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+            else if (st + 2 < nstages)
+                asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        } else {
+            if (st + 3 < nstages)
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (st + 2 < nstages)
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
     }
     }
@@ -434,12 +448,9 @@ static int gs_launch(GemmSplitArgs &g, int tiles_per_wg, hipStream_t st, const c
     g.m16 = (g.M + 15) / 16;
     g.tiles_per_wg = tiles_per_wg;
     const int ntiles = g.tiles_x * g.tiles_w * g.slices;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (rac_first_use_on_device(RAC_ATTR_GEMM_SPLIT))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   GS_STAGES * GS_STAGE);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(gemm_split_kernel, dim3((ntiles + tiles_per_wg - 1) / tiles_per_wg), dim3(768), GS_STAGES * GS_STAGE, st, g);
     return rac_launch_status(what);
 }
@@ -448,8 +459,9 @@ extern "C" int rac_outproj_fwd(const void *z_image, const void *w_image, float *
                                void *stream)
 {
     RAC_CHECK_ARG(z_image && w_image && partials, "rac_outproj_fwd: null pointer");
-    RAC_CHECK_ARG(M >= 1 && N >= 1 && slices >= 1 && K >= 32 && K % (32 * slices) == 0,
-                  "rac_outproj_fwd: M=%d N=%d K=%d slices=%d (K must be a multiple of 32 * slices)", M, N, K, slices);
+    RAC_CHECK_ARG(M >= 1 && N >= 1 && N % 4 == 0 && slices >= 1 && K >= 32 && K % (32 * slices) == 0,
+                  "rac_outproj_fwd: M=%d N=%d K=%d slices=%d (N must be a multiple of 4 -- 16-byte stores --, K of 32 * slices)", M, N, K,
+                  slices);
     GemmSplitArgs g;
     g.x = reinterpret_cast<const char *>(z_image);
     g.w = reinterpret_cast<const char *>(w_image);
@@ -481,12 +493,9 @@ extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const
         chunks = chunks > max_chunks ? max_chunks : chunks;
         a.rows_per_wg = ((M + chunks - 1) / chunks + GW_ROWS - 1) / GW_ROWS * GW_ROWS;
         chunks = (M + a.rows_per_wg - 1) / a.rows_per_wg;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (rac_first_use_on_device(RAC_ATTR_GENERATOR))
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(generator_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       GW_STAGES * GW_STAGE);
-            attr_set = true;
-        }
         hipLaunchKernelGGL(generator_ws_kernel, dim3(fblocks, chunks), dim3(512), GW_STAGES * GW_STAGE, (hipStream_t)stream, a);
         return rac_launch_status("rac_generator_fwd");
     }

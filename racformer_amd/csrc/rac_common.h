@@ -9,6 +9,12 @@
 
 void rac_set_error(const char *fmt, ...);
 
+// Function attributes (the dynamic-LDS limit) are per device: true the first time kernel slot `id` (0..63, one per kernel that
+// raises its limit) is asked for on the CURRENT device, from any thread.  (capi.cpp)
+bool rac_first_use_on_device(int id);
+enum { RAC_ATTR_GEMM_SPLIT = 0, RAC_ATTR_GENERATOR, RAC_ATTR_CONV3X3, RAC_ATTR_CONV3X3S2, RAC_ATTR_MIXING_F32, RAC_ATTR_MIXING_F16,
+       RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV };
+
 #define RAC_CHECK_ARG(cond, ...)            \
     do {                                    \
         if (!(cond)) {                      \

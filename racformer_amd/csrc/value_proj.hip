@@ -196,11 +196,8 @@ extern "C" int rac_value_proj_fwd(const float *x, const void *w_image, float w_a
     ppw = (ppw + VP_ROWS - 1) / VP_ROWS * VP_ROWS;
     a.pixels_per_wg = (int)ppw;
     const unsigned grid = (unsigned)((a.M + ppw - 1) / ppw);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (rac_first_use_on_device(RAC_ATTR_VALUE_PROJ))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(value_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VP_LDS);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(value_proj_kernel, dim3(grid), dim3(512), VP_LDS, (hipStream_t)stream, a);
     return rac_launch_status("rac_value_proj_fwd");
 }

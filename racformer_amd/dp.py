@@ -18,9 +18,15 @@ def shard_indices(num_samples, rank, world_size):
     return idx[rank:total:world_size]
 
 
-def all_gather_detections(det, group=None):
-    """det [S_local, K, 11] on every rank (same shape) -> [world, S_local, K, 11]."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def all_gather_detections(det, group=None, force_collective=False):
+    """det [S_local, K, 11] on every rank (same shape) -> [world, S_local, K, 11].  A world of one rank returns the local
+    block without a collective unless ``force_collective`` (the single-GPU rehearsal of the RCCL path:
+    tests/test_rccl_gpu.py, ``bench.py --force-collective``)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if force_collective:
+            raise RuntimeError("all_gather_detections: force_collective needs an initialised process group")
+        return det[None]
+    if dist.get_world_size(group) == 1 and not force_collective:
         return det[None]
     out = torch.empty((dist.get_world_size(group),) + tuple(det.shape), device=det.device, dtype=det.dtype)
     # per-rank views of one contiguous buffer: portable across RCCL and gloo, one collective

@@ -186,9 +186,19 @@ class RaCFormerSampling(nn.Module):
         # a list of u8 [S,Q,P] tensors, consumed one per call: the camera index every point is to be sampled in, replacing
         # the first-valid-view selection (parity tests impose the reference's own choices: tests/parity.py)
         self.force_views = None
+        # True: the list is walked round and round instead of consumed (one entry per decoder layer, every forward the same:
+        # what a captured plan needs, whose warm-up and capture forwards all have to see the imposed choices)
+        self.force_views_cyclic = False
+        self._force_i = 0
 
     def _next_forced(self):
-        return self.force_views.pop(0) if self.force_views else None
+        if not self.force_views:
+            return None
+        if self.force_views_cyclic:
+            v = self.force_views[self._force_i % len(self.force_views)]
+            self._force_i += 1
+            return v
+        return self.force_views.pop(0)
 
     def init_weights(self):
         bias = self.sampling_offset.bias.data.view(self.depth_num * self.num_groups * self.num_points, 3)
@@ -1328,6 +1338,7 @@ class RaCFormerTransformerDecoder(nn.Module):
         else:
             dev = flat.to(device)
         n0, n1 = td.size, td.size + td_safe.size
+        m0["_rac_meta_block"] = dev if l2i is not None else None      # (racformer_amd/graph.py restages into this block)
         m0["time_diff"] = dev[:n0].view(td.shape)
         m0["time_diff_safe"] = dev[n0:n1].view(td_safe.shape)
         if l2i is not None:

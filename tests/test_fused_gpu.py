@@ -248,11 +248,13 @@ def test_outproj_kernel_vs_float64(M, N, K, S):
 
 
 @pytest.mark.parametrize("M,N,K", [(900, 4096, 256), (900, 65536, 256), (37, 520, 64), (129, 256, 32), (1, 4, 96),
-                                   (900, 2189, 256), (70, 777, 256), (33, 30, 256)])
+                                   (900, 2189, 256), (70, 777, 256), (33, 30, 256), (4000, 2189, 256), (200, 33000, 256)])
 def test_generator_kernel_vs_float64(M, N, K):
     """rac_generator_fwd (the same kernel, persistent over the row tiles of a feature tile, affine epilogue) against float64:
     ragged rows (tiles of unequal height, skipped MFMA tiles), ragged features (N % 256 != 0, N % 4 != 0 with a padded row
-    stride: the 2189 outputs of the sampling Linears, rows cut into chunks), bias, alpha; and the X line image written by
+    stride: the 2189 outputs of the sampling Linears, rows cut into chunks), bias, alpha; more than three row stages per
+    workgroup together with a partial last feature block (M = 4000 / N = 2189, M = 200 / N = 33000: the waves that store
+    nothing there must not run ahead of the X stages -- their counted waits cover the pieces alone); and the X line image written by
     rac_rowgemm_fwd's prologue (K = 256, N % 4 == 0) or rac_add_ln_fwd (N % 4 != 0)."""
     from racformer_amd.fused import SPLIT_ACT_SCALE, generator_fused, pack_gemm_split_weight, row_gemm, row_seg, rowgemm_launch
     g = torch.Generator().manual_seed(M + N)

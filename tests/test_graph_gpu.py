@@ -1,0 +1,101 @@
+"""The captured plan (racformer_amd/graph.py: regroup + prologue + six layers [+ decode] as one HIP-graph submission) against
+the reference's fixtures and the oracle -- the same criteria as the eager plan, through the replayed graph."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restate as R
+from parity import MAX_FLIPPED_POINTS, decoder_parity, detections_parity, fill_rig_module, flipped_points, head_boxes_normalised, kept_rows
+from racformer_amd import synthetic as syn
+from racformer_amd.graph import CapturedForward, CapturedStep
+from racformer_amd.transformer import RaCFormerTransformer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("name,cfg,literal", [("decoder_f8_init.npz", syn.F8, True), ("decoder_f8_3cam_init.npz", syn.F8_3CAM, True),
+                                               ("decoder_f8.npz", syn.F8, False)])
+def test_captured_decoder_vs_reference(golden_dir, name, cfg, literal):
+    """Six free-running layers replayed from the graph (twice: the second replay runs on the first one's buffers) against the
+    reference's CPU forward; the camera choices come out of the replayed kernels' own loc_out."""
+    g = np.load(os.path.join(golden_dir, name))
+    seed = int(g["seed"])
+    tr = fill_rig_module(RaCFormerTransformer(**cfg.transformer_kwargs()).eval(), cfg, g, golden_dir).to(DEV)
+    layer = tr.decoder.decoder_layer
+    qb, qf = (x.to(DEV) for x in syn.make_queries(cfg, seed))
+    feats = [f.to(DEV) for f in syn.make_pyramid(cfg, seed)]
+    lss, radar = syn.make_bev(cfg, seed, 0).to(DEV), syn.make_bev(cfg, seed, 1).to(DEV)
+    metas = syn.make_img_metas(cfg)
+    tr.decoder.stage_metas(metas, 1, torch.device(DEV))
+    layer.sampling.force_views = [t(v).to(DEV).contiguous() for v in g["views"]]      # equal discrete choices on both sides,
+    layer.sampling.force_views_cyclic = True                                          # in the warm-up forwards and the captured one
+    taps = []
+
+    def fn():
+        layer.sampling.capture_loc = taps
+        del taps[:]
+        return tr(qb, qf, list(feats), lss, radar, None, metas)
+
+    cap = CapturedForward(fn, torch.device(DEV))
+    for _ in range(2):
+        cls, box = cap.replay()
+    torch.cuda.synchronize()
+    assert len(taps) == cfg.num_layers
+    views = torch.stack([R.views_of(l.cpu(), cfg.num_cams) for l in taps])
+    nflip = flipped_points(views, g["views"])
+    print(name, "captured plan: own camera choices differing from the reference's, per layer:", nflip)
+    assert sum(nflip) <= MAX_FLIPPED_POINTS
+    decoder_parity(cls.cpu(), box.cpu(), g["cls"], g["box"], what=name + " (captured)", **(dict(tail_budget=None) if literal else {}))
+
+
+def test_captured_step_new_metas_and_detections(golden_dir):
+    """CapturedStep (head + fixed-shape decode): replayed with the metas of the sample it was captured on it reproduces the
+    eager step bit for bit; replayed with ANOTHER sample's timestamps (staged in front of the graph) it matches an eager
+    forward on those metas -- the per-sample host arithmetic is outside the graph, not frozen into it -- and the end-to-end
+    detection list matches the reference head's (head_f8.npz)."""
+    from test_parity_gpu import build_head
+    cfg = syn.F8
+    g = np.load(os.path.join(golden_dir, "head_f8.npz"))
+    seed, wseed = int(g["seed"]), int(g["weight_seed"])
+    head = build_head(cfg, g, seed, wseed)
+    feats = [f.to(DEV) for f in syn.make_pyramid(cfg, seed)]
+    lss, radar = syn.make_bev(cfg, seed, 0).to(DEV), syn.make_bev(cfg, seed, 1).to(DEV)
+    metas = syn.make_img_metas(cfg)
+    with torch.no_grad():
+        eager = head(list(feats), lss, radar, [dict(m) for m in metas])
+        eager_det = head.get_detections_fixed(eager).clone()
+        eager_cls, eager_box = eager["all_cls_scores"].clone(), eager["all_bbox_preds"].clone()
+    cap = CapturedStep(head, feats, lss, radar, metas)
+    preds, det = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(preds["all_cls_scores"], eager_cls) and torch.equal(preds["all_bbox_preds"], eager_box)
+    assert torch.equal(det, eager_det)
+    # against the reference head: a second capture with the reference's camera choices imposed (the comparison of
+    # tests/test_parity_gpu.py::test_head_forward_and_detections_vs_reference, through the replayed graph)
+    smp = head.transformer.decoder.decoder_layer.sampling
+    smp.force_views, smp.force_views_cyclic = [t(v).to(DEV).contiguous() for v in g["views"]], True
+    preds, det = CapturedStep(head, feats, lss, radar, metas).replay()
+    torch.cuda.synchronize()
+    smp.force_views, smp.force_views_cyclic = None, False
+    ref_det = dict(bboxes=g["det_boxes"], scores=g["det_scores"], labels=g["det_labels"])
+    ref_n = head_boxes_normalised(g["all_bbox_preds"], cfg.pc_range)
+    rows = decoder_parity(preds["all_cls_scores"].cpu(), head_boxes_normalised(preds["all_bbox_preds"].cpu(), cfg.pc_range),
+                          g["all_cls_scores"], ref_n, what="head_f8 (captured)")
+    detections_parity(kept_rows(det[0].cpu()), ref_det, what="head_f8 captured end-to-end", allowed_unmatched=3 * rows[-1]["failing"])
+    # another sample's metas (first capture, free-running): frame spacing 0.4 s instead of 0.5 s
+    other = [dict(m) for m in metas]
+    for m in other:
+        m["img_timestamp"] = [10.0 - 0.4 * (i // cfg.num_cams) + 0.001 * (i % cfg.num_cams) for i in range(len(m["img_timestamp"]))]
+    preds2, det2 = cap.replay(img_metas=other)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        eager2 = head(list(feats), lss, radar, [dict(m) for m in other])
+    assert not torch.equal(preds2["all_bbox_preds"], eager_box)
+    assert torch.equal(preds2["all_cls_scores"], eager2["all_cls_scores"]) and torch.equal(preds2["all_bbox_preds"], eager2["all_bbox_preds"])

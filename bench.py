@@ -181,6 +181,42 @@ def stress_block(cfg, device, reps=20):
     b_alg = min(taps, value.numel() * 4) + mloc.numel() * 4 + attn.numel() * 4 + bs * Q * heads * 64 * 4
     out["rac_msda_fwd"] = {"avg_launch_ms": ms, "algorithmic_bytes": b_alg, "achieved": b_alg / (ms * 1e-3) / 1e9,
                            "unit": "GB/s", "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del value
+    # The FUSED kernel (keypoints + projection + view selection + gather) on a scattered-query set: boxes anywhere in the
+    # range (theta, d uniform; z, sizes, yaw, velocity random), the three sampling Linears' outputs ~ N(0,1) (offsets, ray
+    # jitter, level logits -- what a random-feature query would produce), N(0,1) maps, the rig's own cameras and timestamps.
+    # Neighbouring queries then have nothing in common: no L2 locality between the rows of a workgroup.
+    from racformer_amd.fused import sampling4d_fused
+    T, G, NP, D = cfg.num_frames, cfg.num_groups, cfg.num_points, cfg.img_depth_num
+    feats = [torch.randn(S, N, h, w, C, generator=g).to(device) for (h, w) in cfg.fpn_hw]
+    qb = torch.zeros(cfg.batch, Q, 10)
+    qb[..., 0:2] = torch.rand(cfg.batch, Q, 2, generator=g)
+    qb[..., 2] = 0.3 + 0.4 * torch.rand(cfg.batch, Q, generator=g)
+    qb[..., 3:6] = 0.5 + 0.4 * torch.randn(cfg.batch, Q, 3, generator=g)
+    yaw = 2 * np.pi * torch.rand(cfg.batch, Q, generator=g)
+    qb[..., 6], qb[..., 7] = torch.sin(yaw), torch.cos(yaw)
+    qb[..., 8:10] = 2.0 * torch.randn(cfg.batch, Q, 2, generator=g)
+    offs = torch.randn(cfg.batch, Q, G * P * 3, generator=g)
+    rays = torch.randn(cfg.batch, Q, D, generator=g)
+    scl = torch.randn(cfg.batch, Q, G * T * P * L, generator=g)
+    metas = syn.make_img_metas(cfg)
+    ts = np.array([m["img_timestamp"] for m in metas], dtype=np.float64).reshape(cfg.batch, -1, N)
+    td = torch.from_numpy(np.mean(ts[:, :1, :] - ts, axis=-1).astype(np.float32)).to(device)
+    l2i = torch.from_numpy(np.asarray([m["lidar2img"] for m in metas]).astype(np.float32)).to(device)
+    qb, offs, rays, scl = qb.to(device), offs.to(device), rays.to(device), scl.to(device)
+    H_img, W_img = cfg.image_hw
+
+    def fused(debug=False):
+        return sampling4d_fused(feats, qb, offs, rays, scl, td, l2i, T, G, NP, D, list(cfg.pc_range), cfg.d_region_list[0], H_img, W_img,
+                                debug=debug)
+    ms = timed(fused)
+    _, loc_f, _ = fused(debug=True)
+    torch.cuda.synchronize()
+    b_alg, fr = msmv_algorithmic_bytes(loc_f.cpu(), [tuple(f.shape) for f in feats], 4, S * Q * C * P)
+    out["rac_sampling4d_fwd"] = {"avg_launch_ms": ms, "algorithmic_bytes": b_alg, "in_range_fraction": float(np.mean(fr)),
+                                 "achieved": b_alg / (ms * 1e-3) / 1e9, "unit": "GB/s", "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "set": "scattered queries: boxes uniform over the range, random yaw / size / velocity, N(0,1) "
+                                        "offsets and level logits, N(0,1) maps"}
     return out
 
 
@@ -225,10 +261,14 @@ def main():
     ap.add_argument("--feature-dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the uniform-stress timing of the operator kernels")
+    ap.add_argument("--stress-only", action="store_true", help="print the uniform-stress block alone (kernel A/B runs) and exit")
     ap.add_argument("--pregrouped", action="store_true",
                     help="feed the pyramid already in the sampling layout (producer-side layout, row f2): no regroup")
     ap.add_argument("--no-graph", action="store_true",
                     help="time the eager plan (one Python-issued launch per kernel) instead of the captured HIP graph")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="samples in flight per GPU: that many captured plans on streams of their own, replayed round-robin "
+                         "(the latency-bound launches of one sample run beside the bandwidth-bound ones of the other)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the RCCL process group and issue the all-gather even in a world of one rank "
                          "(single-GPU rehearsal of the N > 1 path)")
@@ -266,6 +306,9 @@ def main():
 
     cfg = syn.F8 if args.config == "f8" else syn.F8_3CAM
     fdt = torch.float32 if args.feature_dtype == "f32" else torch.bfloat16
+    if args.stress_only:
+        print(json.dumps({"roofline_stress": stress_block(cfg, device)}))
+        return
     head = build_head(cfg, device, fdt)
     seed = rank  # every rank decodes its own sample
     pyramid = [f.to(device) for f in syn.make_pyramid(cfg, seed)]
@@ -290,10 +333,25 @@ def main():
         # in front of the replay and issues the all-gather behind it
         from racformer_amd.graph import CapturedStep
         captured = CapturedStep(head, pyramid, lss, radar, metas)
+    lanes, turn = [], [0]
+    if captured is not None and args.in_flight > 1:
+        main_stream = torch.cuda.current_stream(device)
+        lanes = [(captured, torch.cuda.Stream(device=device))]
+        lanes += [(CapturedStep(head, pyramid, lss, radar, metas, own_scratch=True), torch.cuda.Stream(device=device))
+                  for _ in range(args.in_flight - 1)]
 
     def step():
         if captured is None:
             return eager_step()
+        if lanes:
+            cap, st = lanes[turn[0] % len(lanes)]
+            turn[0] += 1
+            st.wait_stream(main_stream)
+            with torch.cuda.stream(st):
+                _, det = cap.replay(img_metas=metas)
+            if use_pg:
+                main_stream.wait_stream(st)            # the collective is issued on the main stream
+            return dp.all_gather_detections(det, force_collective=args.force_collective)
         _, det = captured.replay(img_metas=metas)
         return dp.all_gather_detections(det, force_collective=args.force_collective)
 
@@ -417,7 +475,8 @@ def main():
         "config": {"workload": f"racformer_r50_nuimg_704x256_{args.config} query-decoder hot path: regroup + 6 decoder "
                                "layers + NMS-free decode, 1 sample/GPU/step",
                    "queries": cfg.num_query, "cams": cfg.num_cams, "frames": cfg.num_frames,
-                   "levels": cfg.num_levels, "samples_per_gpu": 1, "parallelism": f"dp{world}",
+                   "levels": cfg.num_levels, "samples_per_gpu": 1, "samples_in_flight_per_gpu": max(1, args.in_flight if captured is not None else 1),
+                   "parallelism": f"dp{world}",
                    "pyramid_layout": "pregrouped [B*T*G,N,H,W,C]" if args.pregrouped else "reference [B,T*N,G*C,H,W] (regroup timed)"},
         "roofline": {"bound": "hbm", "kernel": "sampling4d_c64_kernel (rac_sampling4d_fwd: keypoints + projection + view select + gather)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

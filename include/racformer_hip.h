@@ -256,7 +256,8 @@ int rac_gemm_split_pack_fwd(const float *weight, void *image, int N, int K, floa
  *   partials[s][m][n] = sum_{k in slice s} Z[m][k] * W[n][k]        (unscaled: the consumer applies both powers of two)
  *   z_image : device f16 line image [M][K/32][hi 32 | lo 32]   (rac_mixing_fwd's out_split)
  *   w_image : device f16 line image [N][K/32][hi 32 | lo 32]   (rac_gemm_split_pack_fwd)
- *   partials: device f32 [slices][M][N];  K % (32 * slices) == 0 and N % 4 == 0 (16-byte stores).  rac_add_ln_fwd sums the slices. */
+ *   partials: device f32 [slices][M][N];  K % (32 * slices) == 0 (N % 4 == 0 gives aligned 16-byte stores; other N work through
+ *             unaligned stores, slower).  rac_add_ln_fwd sums the slices. */
 int rac_outproj_fwd(const void *z_image, const void *w_image, float *partials, int M, int N, int K, int slices, void *stream);
 
 /* AdaptiveMixing.parameter_generator (nn.Linear(256 -> groups*(64*64 + 128*in_points)), models/racformer_transformer.py:565,589)
@@ -285,7 +286,7 @@ int rac_value_proj_fwd(const float *x, const void *w_image, float w_alpha, const
  * nn.Conv2d of models/racformer_transformer.py:631,655) as an implicit GEMM on the f16 matrix cores with
  * hi/lo-split operands (3 products, fp32 accumulate: fp32-convolution accuracy).  Three calls:
  *   rac_absmax_fwd    amax_out[0] = max(floor_value, max |v| over `num` device arrays) (srcs / counts: HOST arrays;
- *                     16-byte aligned sources); enqueues a 4-byte memset of amax_out first.  Fixes the activations'
+ *                     16-byte aligned sources); a one-thread launch sets amax_out to floor_value first.  Fixes the activations'
  *                     power-of-two scale; floor_value >= 0 covers sources whose bound is known without reading them.
  *   rac_conv_pack_fwd src [N,C,H,W] f32 -> channel range [c_offset, c_offset+C) of the kernel's activation image
  *                     xs = f16 [N][H+2][W+2][c_total/32][2][32] (per pixel and 32-channel chunk: hi, then lo, of

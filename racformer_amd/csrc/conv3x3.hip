@@ -39,6 +39,13 @@ __device__ __forceinline__ float cv_act_scale(float amax)
 }
 
 // ------------------------------------------------------------------------------------------------ absmax
+// (a one-thread launch rather than a memset: inside a captured HIP graph the step then consists of kernel nodes only, whose
+//  order along the stream is the order of execution)
+__global__ void absmax_init_kernel(unsigned *__restrict__ out, unsigned floor_bits)
+{
+    *out = floor_bits;
+}
+
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ src, long n, unsigned *__restrict__ out)
 {
     float m = 0.f;
@@ -428,11 +435,7 @@ extern "C" int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, i
     RAC_CHECK_ARG(num >= 0 && amax_out && floor_value >= 0.f, "rac_absmax_fwd: bad arguments");
     unsigned floor_bits;
     memcpy(&floor_bits, &floor_value, sizeof(floor_bits));
-    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)amax_out, (int)floor_bits, 1, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        rac_set_error("rac_absmax_fwd: %s", hipGetErrorString(e));
-        return (int)e;
-    }
+    hipLaunchKernelGGL(absmax_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned *>(amax_out), floor_bits);
     for (int i = 0; i < num; ++i) {
         RAC_CHECK_ARG(counts[i] >= 0 && (counts[i] == 0 || srcs[i]), "rac_absmax_fwd: source %d", i);
         RAC_CHECK_ARG(((uintptr_t)srcs[i] & 15) == 0, "rac_absmax_fwd: source %d is not 16-byte aligned", i);

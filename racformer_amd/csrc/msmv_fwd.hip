@@ -45,15 +45,32 @@ typedef unsigned int msmv_u4 __attribute__((ext_vector_type(4)));
 
 // Four channels of one tap through the level's buffer descriptor: its range check stands in for the four branches of the
 // bilinear footprint (a tap outside the map carries the offset MSMV_TAP_OUTSIDE and reads as zero).
-template <typename FT>
+#ifndef MSMV_NT_LEVEL0
+#define MSMV_NT_LEVEL0 1   /* measured on SURVEY 8d's uniform-stress set: 122 -> 112 us per launch (60 -> 65 % of the roofline) */
+#endif
+// AUX: cache policy of the load (0 default, 2 = nt: a line that is read once -- the finest level's taps on a scattered set --
+// does not push the coarser levels' maps out of the XCD's L2)
+template <typename FT, int AUX>
 __device__ __forceinline__ rac_f4 msmv_tap(__amdgpu_buffer_rsrc_t rsrc, unsigned off);
 template <>
-__device__ __forceinline__ rac_f4 msmv_tap<float>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+__device__ __forceinline__ rac_f4 msmv_tap<float, 0>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
 {
     return __builtin_bit_cast(rac_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
 }
 template <>
-__device__ __forceinline__ rac_f4 msmv_tap<unsigned short>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+__device__ __forceinline__ rac_f4 msmv_tap<float, 2>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+{
+    return __builtin_bit_cast(rac_f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2));
+}
+template <>
+__device__ __forceinline__ rac_f4 msmv_tap<unsigned short, 2>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+{
+    const msmv_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 2);    // 4 x bf16
+    return (rac_f4){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                    __uint_as_float(r.y & 0xffff0000u)};
+}
+template <>
+__device__ __forceinline__ rac_f4 msmv_tap<unsigned short, 0>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
 {
     const msmv_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);    // 4 x bf16
     return (rac_f4){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
@@ -140,10 +157,17 @@ __global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(con
             for (int l = 0; l < L; ++l) {
                 const msmv_u4 o = *reinterpret_cast<const msmv_u4 *>(e + l * lstride);
                 tw[l] = *reinterpret_cast<const rac_f4 *>(e + l * lstride + 4);
-                v[l][0] = msmv_tap<FT>(rsrc[l], o.x + lane_off);
-                v[l][1] = msmv_tap<FT>(rsrc[l], o.y + lane_off);
-                v[l][2] = msmv_tap<FT>(rsrc[l], o.z + lane_off);
-                v[l][3] = msmv_tap<FT>(rsrc[l], o.w + lane_off);
+                if (l == 0 && MSMV_NT_LEVEL0) {
+                    v[l][0] = msmv_tap<FT, 2>(rsrc[l], o.x + lane_off);
+                    v[l][1] = msmv_tap<FT, 2>(rsrc[l], o.y + lane_off);
+                    v[l][2] = msmv_tap<FT, 2>(rsrc[l], o.z + lane_off);
+                    v[l][3] = msmv_tap<FT, 2>(rsrc[l], o.w + lane_off);
+                } else {
+                    v[l][0] = msmv_tap<FT, 0>(rsrc[l], o.x + lane_off);
+                    v[l][1] = msmv_tap<FT, 0>(rsrc[l], o.y + lane_off);
+                    v[l][2] = msmv_tap<FT, 0>(rsrc[l], o.z + lane_off);
+                    v[l][3] = msmv_tap<FT, 0>(rsrc[l], o.w + lane_off);
+                }
             }
             msmv_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
 #pragma unroll

@@ -37,6 +37,9 @@ def box_prep(query_bbox, pc_range):
     return table
 
 
+_checked_views = set()
+
+
 def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, time_diff, lidar2img,
                      num_frames, num_groups, num_points, depth_num, pc_range, d_region, image_h, image_w,
                      eps=1e-5, debug=False, box_table=None, view_in=None):
@@ -67,8 +70,13 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
     if view_in is not None:
         if view_in.dtype != torch.uint8 or tuple(view_in.shape) != (S, Q, P) or not view_in.is_cuda or not view_in.is_contiguous():
             raise RuntimeError(f"sampling4d_fused: view_in must be a contiguous CUDA uint8 [{S},{Q},{P}] tensor")
-        if int(view_in.max()) >= N:
-            raise RuntimeError("sampling4d_fused: view_in holds a camera index >= N")
+        key = (view_in.data_ptr(), view_in._version, N)
+        if key not in _checked_views:        # (a host read: once per tensor, so that a captured plan's forwards issue none)
+            if int(view_in.max()) >= N:
+                raise RuntimeError("sampling4d_fused: view_in holds a camera index >= N")
+            if len(_checked_views) > 256:
+                _checked_views.clear()
+            _checked_views.add(key)
     ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
     hw = (ctypes.c_int32 * (2 * L))(*[int(x) for f in feats for x in f.shape[2:4]])
     pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
@@ -388,6 +396,24 @@ def pack_conv3x3_weight(weight, cout=256):
 
 
 _conv_images = {}
+_scratch_ns = [None]
+
+
+class scratch_namespace:
+    """Reusable device scratch (the convolution kernels' activation images) is shared by every forward of a process -- fine while
+    forwards follow each other on one stream.  A captured plan that is replayed BESIDE another one (racformer_amd/graph.py, several
+    samples in flight on streams of their own) has to own its scratch: forwards run inside ``with scratch_namespace(key)`` get
+    buffers of that namespace."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        self.prev, _scratch_ns[0] = _scratch_ns[0], self.key
+        return self
+
+    def __exit__(self, *exc):
+        _scratch_ns[0] = self.prev
 
 
 class ConvImage:
@@ -398,7 +424,7 @@ class ConvImage:
 
     def __init__(self, N, H, W, cin, device):
         self.N, self.H, self.W, self.cin, self.dev = N, H, W, cin, device
-        key = (N, H, W, cin, str(device))
+        key = (N, H, W, cin, str(device), _scratch_ns[0])
         xs = _conv_images.get(key)
         if xs is None:
             xs = _conv_images[key] = torch.zeros(N, H + 2, W + 2, cin // 32, 2, 32, device=device, dtype=torch.float16)

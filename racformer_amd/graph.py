@@ -48,7 +48,12 @@ class CapturedForward:
 class CapturedStep:
     """head.forward + head.get_detections_fixed of one sample per GPU as a replayable HIP graph."""
 
-    def __init__(self, head, mlvl_feats, lss_bev_feats, radar_bev_feats, img_metas, warmup=2, decode=True):
+    _serial = [0]
+
+    def __init__(self, head, mlvl_feats, lss_bev_feats, radar_bev_feats, img_metas, warmup=2, decode=True, own_scratch=False):
+        """``own_scratch``: the plan gets reusable scratch buffers of its own (racformer_amd.fused.scratch_namespace) -- required
+        for a plan that is replayed on another stream beside other plans (several samples in flight); plans that follow each
+        other on one stream share them."""
         if not lss_bev_feats.is_cuda:
             raise RuntimeError("racformer_amd.graph: capture needs device tensors (the hot path has no CPU fallback)")
         self.head, self.decode = head, decode
@@ -66,7 +71,10 @@ class CapturedStep:
             preds = head(list(self.inputs[0]), self.inputs[1], self.inputs[2], self.metas)
             return preds, (head.get_detections_fixed(preds) if decode else None)
 
-        self._cap = CapturedForward(run, self.device, warmup)
+        from .fused import scratch_namespace
+        CapturedStep._serial[0] += 1
+        with scratch_namespace(("captured_step", CapturedStep._serial[0]) if own_scratch else None):
+            self._cap = CapturedForward(run, self.device, warmup)
         self.graph = self._cap.graph
         self.preds, self.det = self._cap.outputs
 

@@ -122,7 +122,8 @@ def test_fpn_output_writer_vs_float64_conv_and_oracle_regroup(images, hw):
     assert tuple(got.shape) == tuple(want_g.shape) == (images // cfg.num_cams * 4, cfg.num_cams, hw[0], hw[1], 64)
     e_kernel = (got.double() - want_g).abs().max().item()
     e_fp32 = (fp32.double() - want).abs().max().item()
-    assert e_kernel < 4 * e_fp32 + 1e-6, (e_kernel, e_fp32)
+    # fp32-convolution accuracy: within a few fp32 roundings of the 2304-term sums (a CPU fp32 convolution is the yardstick)
+    assert e_kernel < max(4 * e_fp32, 3e-6 * float(want.abs().max())) + 1e-6, (e_kernel, e_fp32)
 
 
 def test_fpn_output_writer_wide_rows_f8_level0():

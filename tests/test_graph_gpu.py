@@ -57,7 +57,7 @@ def test_captured_decoder_vs_reference(golden_dir, name, cfg, literal):
 
 def test_captured_step_new_metas_and_detections(golden_dir):
     """CapturedStep (head + fixed-shape decode): replayed with the metas of the sample it was captured on it reproduces the
-    eager step bit for bit; replayed with ANOTHER sample's timestamps (staged in front of the graph) it matches an eager
+    eager step bit for bit; replayed with ANOTHER sample's timestamps (staged in front of the graph) it follows an eager
     forward on those metas -- the per-sample host arithmetic is outside the graph, not frozen into it -- and the end-to-end
     detection list matches the reference head's (head_f8.npz)."""
     from test_parity_gpu import build_head
@@ -99,3 +99,39 @@ def test_captured_step_new_metas_and_detections(golden_dir):
         eager2 = head(list(feats), lss, radar, [dict(m) for m in other])
     assert not torch.equal(preds2["all_bbox_preds"], eager_box)
     assert torch.equal(preds2["all_cls_scores"], eager2["all_cls_scores"]) and torch.equal(preds2["all_bbox_preds"], eager2["all_bbox_preds"])
+
+
+def test_plans_in_flight_side_by_side_match_the_single_plan(golden_dir):
+    """Several samples in flight (bench.py --in-flight N): captured plans with scratch of their own replayed on streams of
+    their own, interleaved and overlapping, each reproduce the single plan's outputs bit for bit (a shared scratch buffer or
+    any other cross-plan state would show here)."""
+    from test_parity_gpu import build_head
+    cfg = syn.F8
+    g = np.load(os.path.join(golden_dir, "head_f8.npz"))
+    seed, wseed = int(g["seed"]), int(g["weight_seed"])
+    head = build_head(cfg, g, seed, wseed)
+    feats = [f.to(DEV) for f in syn.make_pyramid(cfg, seed)]
+    lss, radar = syn.make_bev(cfg, seed, 0).to(DEV), syn.make_bev(cfg, seed, 1).to(DEV)
+    metas = syn.make_img_metas(cfg)
+    other = [dict(m) for m in metas]
+    for m in other:
+        m["img_timestamp"] = [10.0 - 0.4 * (i // cfg.num_cams) + 0.001 * (i % cfg.num_cams) for i in range(len(m["img_timestamp"]))]
+    single = CapturedStep(head, feats, lss, radar, metas)
+    want = []
+    for ms in (metas, other):
+        p, d = single.replay(img_metas=ms)
+        torch.cuda.synchronize()
+        want.append((p["all_bbox_preds"].clone(), d.clone()))
+    assert not torch.equal(want[0][0], want[1][0])
+    lanes = [(CapturedStep(head, feats, lss, radar, metas, own_scratch=True), torch.cuda.Stream()) for _ in range(3)]
+    main = torch.cuda.current_stream()
+    for rnd in range(4):
+        got = []
+        for i, (cap, st) in enumerate(lanes):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                p, d = cap.replay(img_metas=(metas, other)[(i + rnd) % 2])
+            got.append(((i + rnd) % 2, p, d))
+        torch.cuda.synchronize()
+        for which, p, d in got:
+            assert torch.equal(p["all_bbox_preds"], want[which][0]) and torch.equal(d, want[which][1]), (rnd, which)

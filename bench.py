@@ -266,7 +266,7 @@ def main():
                     help="feed the pyramid already in the sampling layout (producer-side layout, row f2): no regroup")
     ap.add_argument("--no-graph", action="store_true",
                     help="time the eager plan (one Python-issued launch per kernel) instead of the captured HIP graph")
-    ap.add_argument("--in-flight", type=int, default=1,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="samples in flight per GPU: that many captured plans on streams of their own, replayed round-robin "
                          "(the latency-bound launches of one sample run beside the bandwidth-bound ones of the other)")
     ap.add_argument("--force-collective", action="store_true",
@@ -376,7 +376,20 @@ def main():
     host_elapsed = time.perf_counter() - t0     # the host has enqueued every step (it runs ahead of the GPU unless it is the limiter)
     fence()
     elapsed = time.perf_counter() - t0
+    single = lanes_agree = None
     if captured is not None:
+        if lanes:
+            # the lanes ran the same sample: their detections must be the same bits (a cross-plan race would show here) ...
+            ref_det = lanes[0][0].det
+            lanes_agree = all(bool(torch.equal(cap.det, ref_det)) for cap, _ in lanes)
+            # ... and the same K steps with ONE plan in flight: the latency-bound figure beside the throughput one
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                captured.replay(img_metas=metas)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            single = {"value": args.steps / dt1, "unit": "samples/s", "ms_per_step": 1e3 * dt1 / args.steps,
+                      "note": "one captured plan in flight (each sample's kernels run alone): per-sample latency"}
         _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "msmv_fwd"))
         for _ in range(args.steps):
             eager_step()
@@ -466,8 +479,11 @@ def main():
         "host_enqueue_ms_per_step": 1e3 * host_elapsed / args.steps,
         "submission": "eager: one launch per kernel from Python" if captured is None else
                       "HIP graph: the step's kernels captured once (racformer_amd/graph.py), one replay per step; metas staged in "
-                      "front of it, all-gather behind it",
+                      "front of it, all-gather behind it" + (f"; {len(lanes)} plans on streams of their own, replayed round-robin, so "
+                      "that up to that many samples are in flight per GPU (the latency-bound launches of one sample run beside the "
+                      "bandwidth-bound ones of another)" if lanes else ""),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "collective": collective,
+        "one_sample_in_flight": single, "lanes_agree_bitwise": lanes_agree,
         "dtype": "f32" if fdt == torch.float32 else "bf16-features/f32-math", "data": "synthetic",
         "arithmetic_note": "fp32 storage and fp32-accurate results throughout; the largest contractions run on the 16-bit "
                            "matrix cores as split-precision products (operands = sums of f16/bf16 terms, fp32 accumulate, "

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
     // phase C: a group walks its list (frame-major: the chip works on (nearly) one frame at a time, which the L2s /
     // Infinity Cache hold better than all of them), BEV_U keypoints = 4 * BEV_U taps in flight.  Per tap: one add for
     // the lane's channel offset, one buffer load, two packed FMAs -- the gather runs at the L1 rate, not the VALU's.
-    bev_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    rac_acc4 acc4 = rac_acc4_zero();
     const bool live = k < nitems;
     if (live) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.value), 0, a.value_bytes, 0x00020000);
@@ -333,14 +333,13 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
                 const float w4[4] = {tw[u].x, tw[u].y, tw[u].z, tw[u].w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const bev_f2 w2 = {w4[c], w4[c]};
-                    acc01 = __builtin_elementwise_fma((bev_f2){v[u][c].x, v[u][c].y}, w2, acc01);
-                    acc23 = __builtin_elementwise_fma((bev_f2){v[u][c].z, v[u][c].w}, w2, acc23);
+                    rac_tap_fma(acc4, v[u][c].x, v[u][c].y, v[u][c].z, v[u][c].w, w4[c]);
                 }
             }
         }
     }
-    const rac_f4 acc = {acc01.x, acc01.y, acc23.x, acc23.y};
+    rac_f4 acc;
+    rac_acc4_get(acc4, acc.x, acc.y, acc.z, acc.w);
     // phase D: fixed-order sum of the four point subsets (deterministic, no atomics)
     *reinterpret_cast<rac_f4 *>(spart + (k * BEV_TS + ts) * 64 + c4 * 4) = acc;
     __syncthreads();

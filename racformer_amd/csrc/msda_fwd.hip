@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d64_kernel(const MsdaArgs a)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.value), 0, a.value_bytes, 0x00020000);
     const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
     const float *e = stab + grp * LPp * 8;      // same address for the 16 lanes of the group
-    msda_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    rac_acc4 acc4 = rac_acc4_zero();
     for (int p0 = 0; p0 < LPp; p0 += 4) {       // 4 points = 16 taps in flight per lane; per tap one add, one load, two packed FMAs
         rac_f4 v[4][4], tw[4];
 #pragma unroll
@@ -128,13 +128,13 @@ __global__ __launch_bounds__(256) void msda_fwd_d64_kernel(const MsdaArgs a)
             const float w4[4] = {tw[k].x, tw[k].y, tw[k].z, tw[k].w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const msda_f2 w2 = {w4[c], w4[c]};
-                acc01 = __builtin_elementwise_fma((msda_f2){v[k][c].x, v[k][c].y}, w2, acc01);
-                acc23 = __builtin_elementwise_fma((msda_f2){v[k][c].z, v[k][c].w}, w2, acc23);
+                rac_tap_fma(acc4, v[k][c].x, v[k][c].y, v[k][c].z, v[k][c].w, w4[c]);
             }
         }
     }
-    *reinterpret_cast<rac_f4 *>(a.out + (item0 + grp) * 64 + c4 * 4) = (rac_f4){acc01.x, acc01.y, acc23.x, acc23.y};
+    rac_f4 r;
+    rac_acc4_get(acc4, r.x, r.y, r.z, r.w);
+    *reinterpret_cast<rac_f4 *>(a.out + (item0 + grp) * 64 + c4 * 4) = r;
 }
 
 template <typename FT>

@@ -169,26 +169,26 @@ __global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(con
                     v[l][3] = msmv_tap<FT, 0>(rsrc[l], o.w + lane_off);
                 }
             }
-            msmv_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+            rac_acc4 acc4 = rac_acc4_zero();
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const float w4[4] = {tw[l].x, tw[l].y, tw[l].z, tw[l].w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const msmv_f2 w2 = {w4[c], w4[c]};
-                    acc01 = __builtin_elementwise_fma((msmv_f2){v[l][c].x, v[l][c].y}, w2, acc01);
-                    acc23 = __builtin_elementwise_fma((msmv_f2){v[l][c].z, v[l][c].w}, w2, acc23);
+                    rac_tap_fma(acc4, v[l][c].x, v[l][c].y, v[l][c].z, v[l][c].w, w4[c]);
                 }
             }
             if (act) {
+                rac_f4 r;
+                rac_acc4_get(acc4, r.x, r.y, r.z, r.w);
                 if (OUT_CL) {
-                    *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = (rac_f4){acc01.x, acc01.y, acc23.x, acc23.y};
+                    *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = r;
                 } else {
                     float *o = a.out + out_row + (size_t)(c4 * 4) * P + p;
-                    o[0] = acc01.x;
-                    o[(size_t)P] = acc01.y;
-                    o[(size_t)2 * P] = acc23.x;
-                    o[(size_t)3 * P] = acc23.y;
+                    o[0] = r.x;
+                    o[(size_t)P] = r.y;
+                    o[(size_t)2 * P] = r.z;
+                    o[(size_t)3 * P] = r.w;
                 }
             }
         }

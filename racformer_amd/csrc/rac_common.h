@@ -59,6 +59,55 @@ __device__ __forceinline__ rac_f4 rac_ld4(const unsigned short *p)
     return o;
 }
 
+// Four channels of one bilinear tap into a lane's running sums (the gather kernels' inner operation).
+// Scalar v_fma_f32, deliberately NOT v_pk_fma_f32 (two channels per instruction, what round 2 used): beside another stream's
+// MFMA kernels (mixing_c64_f16x3_kernel, conv3x3_f16x3_kernel -- several samples in flight, racformer_amd/graph.py) the packed
+// form produced wrong sums in 4-lane granules in every gather kernel while the scalar form never did (tools/dbg_race*.py:
+// rac_msmv_fwd beside a looping mixing kernel, 110 of 120 launches deviating with v_pk_fma_f32, 0 of 120 with v_fma_f32; same
+// loads, same waits, plain global loads instead of buffer loads made no difference).  Same rounding either way (IEEE fma per
+// component), so results are bit-identical to round 2's.
+#ifndef RAC_GATHER_PACKED_FMA
+#define RAC_GATHER_PACKED_FMA 0
+#endif
+typedef float rac_f2v __attribute__((ext_vector_type(2)));
+struct rac_acc4 {
+#if RAC_GATHER_PACKED_FMA
+    rac_f2v a01, a23;
+#else
+    float a0, a1, a2, a3;
+#endif
+};
+__device__ __forceinline__ rac_acc4 rac_acc4_zero()
+{
+#if RAC_GATHER_PACKED_FMA
+    return rac_acc4{(rac_f2v){0.f, 0.f}, (rac_f2v){0.f, 0.f}};
+#else
+    return rac_acc4{0.f, 0.f, 0.f, 0.f};
+#endif
+}
+__device__ __forceinline__ void rac_tap_fma(rac_acc4 &acc, float x, float y, float z, float w4, float w)
+{
+#if RAC_GATHER_PACKED_FMA
+    const rac_f2v w2 = {w, w};
+    acc.a01 = __builtin_elementwise_fma((rac_f2v){x, y}, w2, acc.a01);
+    acc.a23 = __builtin_elementwise_fma((rac_f2v){z, w4}, w2, acc.a23);
+#else
+    acc.a0 = __builtin_fmaf(x, w, acc.a0);
+    acc.a1 = __builtin_fmaf(y, w, acc.a1);
+    acc.a2 = __builtin_fmaf(z, w, acc.a2);
+    acc.a3 = __builtin_fmaf(w4, w, acc.a3);
+    asm volatile("" : "+v"(acc.a0), "+v"(acc.a1), "+v"(acc.a2), "+v"(acc.a3));   // (keeps the SLP vectoriser from re-packing them)
+#endif
+}
+__device__ __forceinline__ void rac_acc4_get(const rac_acc4 &acc, float &x, float &y, float &z, float &w)
+{
+#if RAC_GATHER_PACKED_FMA
+    x = acc.a01.x; y = acc.a01.y; z = acc.a23.x; w = acc.a23.y;
+#else
+    x = acc.a0; y = acc.a1; z = acc.a2; w = acc.a3;
+#endif
+}
+
 // f32 = hi + lo, both f16 (round-to-nearest): hi carries 11 significant bits, lo the next 11.
 struct alignas(8) rac_h4 {
     _Float16 x, y, z, w;

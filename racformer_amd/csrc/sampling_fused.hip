@@ -288,19 +288,21 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
                 v[l][2] = s4d_tap<FT>(rsrc[l], o.z + lane_off);
                 v[l][3] = s4d_tap<FT>(rsrc[l], o.w + lane_off);
             }
-            s4d_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+            rac_acc4 acc4 = rac_acc4_zero();
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const float w4[4] = {tw[l].x, tw[l].y, tw[l].z, tw[l].w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const s4d_f2 w2 = {w4[c], w4[c]};
-                    acc01 = __builtin_elementwise_fma((s4d_f2){v[l][c].x, v[l][c].y}, w2, acc01);
-                    acc23 = __builtin_elementwise_fma((s4d_f2){v[l][c].z, v[l][c].w}, w2, acc23);
+                    rac_tap_fma(acc4, v[l][c].x, v[l][c].y, v[l][c].z, v[l][c].w, w4[c]);
                 }
             }
             if (act)
-                *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = (rac_f4){acc01.x, acc01.y, acc23.x, acc23.y};
+            {
+                rac_f4 r;
+                rac_acc4_get(acc4, r.x, r.y, r.z, r.w);
+                *reinterpret_cast<rac_f4 *>(a.out + out_row + (size_t)p * 64 + c4 * 4) = r;
+            }
         }
     }
 }

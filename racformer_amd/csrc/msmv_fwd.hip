@@ -100,6 +100,9 @@ __global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(con
     const int lstride = MSMV_ROWS * P * 8;
     const size_t row0 = (size_t)s * a.Q + q0;
     for (int i = tid; i < nrows * P; i += 256) {
+        // (products and differences rounded one by one, as the reference kernel's statements read and as the oracle computes them:
+        //  a contracted fma(v, H-1, -floor) moves a bilinear weight by an ulp of the pixel coordinate -- 1e-5 of a pixel at W = 176)
+#pragma clang fp contract(off)
         const float *lp = a.loc + (row0 * P + i) * 3;
         const float *wp = a.w + (row0 * P + i) * L;
         const float lu = lp[0], lv = lp[1];

@@ -126,14 +126,16 @@ int rac_box_prep_fwd(const float *query_bbox, float *table, int num_boxes, const
  *                  (sparsebev_sampling.py:97-110).  NULL on the product path; parity tests pass the reference's own
  *                  choices to take the path's one discontinuous step out of a comparison.  loc_out then still reports
  *                  the kernel's OWN choice in its third component (and the imposed view's u, v).
- *   pc_range (6), depth_base (D = torch.linspace(-d_region,d_region,D)): HOST pointers */
+ *   pc_range (6), depth_base (D = torch.linspace(-d_region,d_region,D)): HOST pointers
+ *   compact      : 1 = the variant that sets points without any tap aside (rigs that do not cover the full circle), 0 = plain,
+ *                  -1 = decide by the number of cameras (<= 3).  Same results either way. */
 int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox,
                        const float *box_table, const float *offsets, const float *ray_logits, const float *scale_logits,
                        const float *time_diff, const float *lidar2img, float *out, float *loc_out,
                        float *w_out, const unsigned char *view_in, int ld_off, int ld_ray, int ld_scale, int B, int T, int N,
                        int G, int Q,
                        int NP, int D, int C, const float *pc_range, const float *depth_base, float d_region,
-                       float image_h, float image_w, float eps, int dtype, void *stream);
+                       float image_h, float image_w, float eps, int dtype, int compact, void *stream);
 
 /* BEV deformable cross-attention of one decoder layer, fully fused (keypoints -> per-frame
  * deformable attention -> softmax-over-frames fusion).  Replaces BEVSampling.inner_forward's keypoint

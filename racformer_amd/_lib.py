@@ -26,7 +26,7 @@ SIGNATURES = {
     "rac_regroup_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rac_regroup_multi_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rac_box_prep_fwd": (_i, [_vp, _vp, _i, _vp, _vp]),
-    "rac_sampling4d_fwd": (_i, [_vp, _vp, _i] + [_vp] * 11 + [_i] * 3 + [_i] * 8 + [_vp, _vp] + [_f] * 4 + [_i, _vp]),
+    "rac_sampling4d_fwd": (_i, [_vp, _vp, _i] + [_vp] * 11 + [_i] * 3 + [_i] * 8 + [_vp, _vp] + [_f] * 4 + [_i, _i, _vp]),
     "rac_msmv_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp] + [_i] * 5 + [_vp]),
     "rac_msda_bwd": (_i, [_vp] * 9 + [_i] * 7 + [_vp]),
     "rac_bev_pool_v2_fwd": (_i, [_vp] * 8 + [_i, _i, _vp]),

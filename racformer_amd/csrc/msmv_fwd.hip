@@ -28,7 +28,7 @@ struct MsmvArgs {
     const void *feat[RAC_MAX_LEVELS];
     int H[RAC_MAX_LEVELS];
     int W[RAC_MAX_LEVELS];
-    unsigned feat_bytes[RAC_MAX_LEVELS];   // size of each level's buffer (the buffer descriptors' ranges; C = 64 path)
+    unsigned feat_bytes[RAC_MAX_LEVELS];   // size of one slot's N maps of each level (the buffer descriptors' ranges; C = 64 path)
     const float *loc;
     const float *w;
     float *out;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(con
             const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
             const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
             const unsigned pix_bytes = (unsigned)(64 * sizeof(FT));
-            const unsigned mbase = (unsigned)(s * a.N + view) * (unsigned)(H * W) * pix_bytes;   // map (slot, camera) of the level
+            const unsigned mbase = (unsigned)view * (unsigned)(H * W) * pix_bytes;   // camera's map inside the slot's block of the level
             msmv_u4 off;
             off.x = t_ok && l_ok ? mbase + (unsigned)(h_low * W + w_low) * pix_bytes : MSMV_TAP_OUTSIDE;
             off.y = t_ok && r_ok ? mbase + (unsigned)(h_low * W + w_high) * pix_bytes : MSMV_TAP_OUTSIDE;
@@ -138,7 +138,10 @@ __global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(con
     __amdgpu_buffer_rsrc_t rsrc[L];
 #pragma unroll
     for (int l = 0; l < L; ++l)
-        rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.feat[l]), 0, a.feat_bytes[l], 0x00020000);
+        // (one descriptor per level over THIS SLOT's N maps: offsets are relative to the slot, so only a slot's bytes -- not the whole
+        //  level's, B * T * G slots -- have to stay below the 31-bit tap offsets)
+        rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.feat[l]) + (size_t)s * a.feat_bytes[l]), 0,
+                                                    a.feat_bytes[l], 0x00020000);
     const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
     // wave w gathers rows w, w+4 of the workgroup; per tap: one add for the lane's channel offset, one buffer load, two
     // packed FMAs; 16 taps (4 levels x 4) in flight per lane
@@ -285,7 +288,7 @@ extern "C" int rac_msmv_fwd(const void *const *feats, const int32_t *hw, int L, 
         a.feat[l] = feats[l];
         a.H[l] = hw[2 * l];
         a.W[l] = hw[2 * l + 1];
-        const size_t bytes = (size_t)S * N * a.H[l] * a.W[l] * C * (dtype == RAC_F32 ? 4 : 2);
+        const size_t bytes = (size_t)N * a.H[l] * a.W[l] * C * (dtype == RAC_F32 ? 4 : 2);        // one slot's maps
         a.feat_bytes[l] = bytes < (size_t)MSMV_TAP_OUTSIDE ? (unsigned)bytes : 0u;    // 0: too large for the 31-bit tap offsets
     }
     for (int l = L; l < RAC_MAX_LEVELS; ++l) {

@@ -41,7 +41,7 @@ struct S4dArgs {
     const void *feat[RAC_MAX_LEVELS];
     int H[RAC_MAX_LEVELS];
     int W[RAC_MAX_LEVELS];
-    unsigned feat_bytes[RAC_MAX_LEVELS];  // size of each level's buffer (the buffer descriptors' ranges)
+    unsigned feat_bytes[RAC_MAX_LEVELS];  // size of one slot's N maps of each level (the buffer descriptors' ranges)
     const float *qbox;       // [B,Q,10]
     const float *box;        // [B,Q,8] from rac_box_prep_fwd (cx,cy,cz,w,l,h,cos,sin)
     const float *off;        // [B,Q,G*P*3]
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
             const bool t_ok = in && h_low >= 0, b_ok = in && h_high <= H - 1;
             const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
             const unsigned pix_bytes = (unsigned)(64 * sizeof(FT));
-            const unsigned mbase = (unsigned)(s * a.N + view) * (unsigned)(H * W) * pix_bytes;   // map (slot, camera) of the level
+            const unsigned mbase = (unsigned)view * (unsigned)(H * W) * pix_bytes;   // camera's map inside the slot's block of the level
             s4d_u4 off;
             off.x = t_ok && l_ok ? mbase + (unsigned)(h_low * W + w_low) * pix_bytes : S4D_TAP_OUTSIDE;
             off.y = t_ok && r_ok ? mbase + (unsigned)(h_low * W + w_high) * pix_bytes : S4D_TAP_OUTSIDE;
@@ -247,7 +247,10 @@ __global__ __launch_bounds__(256, (L <= 4 ? S4D_WPS : 3)) void sampling4d_c64_ke
     __amdgpu_buffer_rsrc_t rsrc[L];
 #pragma unroll
     for (int l = 0; l < L; ++l)
-        rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.feat[l]), 0, a.feat_bytes[l], 0x00020000);
+        // (one descriptor per level over THIS SLOT's N maps: offsets are relative to the slot, so only a slot's bytes -- not the whole
+        //  level's, B * T * G slots -- have to stay below the 31-bit tap offsets)
+        rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.feat[l]) + (size_t)s * a.feat_bytes[l]), 0,
+                                                    a.feat_bytes[l], 0x00020000);
     const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
     // wave w gathers rows w, w+4, ... of the workgroup's S4D_ROWS queries: the keypoint prologue above (one pass, its
     // latency independent of the number of keypoints up to 256) is paid once per S4D_ROWS / 4 gather rounds.  Per tap:
@@ -314,8 +317,9 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
                                   float *w_out, const unsigned char *view_in, int ld_off, int ld_ray, int ld_scale, int B, int T, int N, int G, int Q, int NP,
                                   int D, int C,
                                   const float *pc_range, const float *depth_base, float d_region, float image_h,
-                                  float image_w, float eps, int dtype, void *stream)
+                                  float image_w, float eps, int dtype, int compact, void *stream)
 {
+    RAC_CHECK_ARG(compact >= -1 && compact <= 1, "rac_sampling4d_fwd: compact=%d (-1 automatic, 0 plain, 1 compact)", compact);
     RAC_CHECK_ARG(L == 2 || L == 4 || L == 5, "rac_sampling4d_fwd: L=%d (supported: 2, 4, 5)", L);
     RAC_CHECK_ARG(C == 64, "rac_sampling4d_fwd: C=%d (the fused kernel is built for 64 channels per group)", C);
     RAC_CHECK_ARG(B >= 0 && Q >= 0 && T >= 1 && N >= 1 && N <= S4D_MAX_CAMS && G >= 1 && NP >= 1 && D >= 1 &&
@@ -343,8 +347,8 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
         a.feat[l] = feats[l];
         a.H[l] = hw[2 * l];
         a.W[l] = hw[2 * l + 1];
-        const size_t bytes = (size_t)B * T * G * N * a.H[l] * a.W[l] * 64 * (dtype == RAC_F32 ? 4 : 2);
-        RAC_CHECK_ARG(bytes < (size_t)S4D_TAP_OUTSIDE, "rac_sampling4d_fwd: level %d holds %zu bytes (the tap offsets are 31-bit)", l, bytes);
+        const size_t bytes = (size_t)N * a.H[l] * a.W[l] * 64 * (dtype == RAC_F32 ? 4 : 2);      // one slot's maps
+        RAC_CHECK_ARG(bytes < (size_t)S4D_TAP_OUTSIDE, "rac_sampling4d_fwd: a slot of level %d holds %zu bytes (the tap offsets are 31-bit)", l, bytes);
         a.feat_bytes[l] = (unsigned)bytes;
     }
     a.qbox = query_bbox; a.box = box_table; a.off = offsets; a.ray = ray_logits; a.scale = scale_logits;
@@ -363,14 +367,17 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
     const size_t lds = ((size_t)a.rows * P * 8 * L + (size_t)N * 16) * sizeof(float) + 2 * (size_t)a.rows * P;
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_sampling4d_fwd: P=%d x L=%d too large for the LDS tap table", P, L);
     hipStream_t st = (hipStream_t)stream;
-    // rigs whose cameras do not cover the full circle (N <= 3 here) leave about half of the points without any tap: compact them
+    // Rigs whose cameras do not cover the full circle leave many points without any tap; the COMPACT variant walks only the others
+    // (3-cam rig: 76.8 -> 67.9 us) and costs 2.5 us where every point is live.  The caller decides from the rig's measured
+    // coverage (RaCFormerTransformerDecoder.stage_metas: share of a ring of probe points some camera sees); -1 = no measurement
+    // at hand: by the number of cameras.
 #ifndef S4D_COMPACT_MAX_CAMS
 #define S4D_COMPACT_MAX_CAMS 3
 #endif
-    const bool compact = N <= S4D_COMPACT_MAX_CAMS && P <= 64;
+    const bool use_compact = (compact < 0 ? N <= S4D_COMPACT_MAX_CAMS : compact == 1) && P <= 64;
 #define S4D_LAUNCH(FT, LL)                                                                                           \
     do {                                                                                                             \
-        if (compact) hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL, true>), dim3(nb), dim3(256), lds, st, a);     \
+        if (use_compact) hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL, true>), dim3(nb), dim3(256), lds, st, a);     \
         else hipLaunchKernelGGL((sampling4d_c64_kernel<FT, LL, false>), dim3(nb), dim3(256), lds, st, a);            \
     } while (0)
     if (dtype == RAC_F32) {

@@ -42,10 +42,11 @@ _checked_views = set()
 
 def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, time_diff, lidar2img,
                      num_frames, num_groups, num_points, depth_num, pc_range, d_region, image_h, image_w,
-                     eps=1e-5, debug=False, box_table=None, view_in=None):
+                     eps=1e-5, debug=False, box_table=None, view_in=None, compact=None):
     """-> [B,Q,G,T*P,C] (and, with debug=True, the kernel's own locations [S,Q,P,3] and softmaxed scale
     weights [S,Q,P,L] for parity checks).  ``view_in`` (u8 [S,Q,P], parity tests only): camera index per point that
-    replaces the kernel's own first-valid-view selection."""
+    replaces the kernel's own first-valid-view selection.  ``compact``: True / False selects the kernel variant that sets points
+    without any tap aside (rigs that do not cover the full circle); None: by the number of cameras."""
     feats = list(mlvl_feats)
     L = len(feats)
     _lib.require_gpu(*feats, query_bbox, time_diff, lidar2img, what="sampling4d_fused")
@@ -87,7 +88,7 @@ def sampling4d_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, 
         ptrs, hw, L, _lib.ptr(query_bbox), _lib.ptr(box_table), p_off, p_ray, p_sc, _lib.ptr(time_diff), _lib.ptr(lidar2img),
         _lib.ptr(out), _lib.ptr(loc_out) if debug else None, _lib.ptr(w_out) if debug else None,
         _lib.ptr(view_in) if view_in is not None else None, ld_off, ld_ray, ld_sc, B, T, N, G, Q, NP, D, C, pc, _depth_base(float(d_region), D), float(d_region),
-        float(image_h), float(image_w), float(eps), _lib.dtype_code(feats[0]), _lib.stream_ptr())
+        float(image_h), float(image_w), float(eps), _lib.dtype_code(feats[0]), -1 if compact is None else int(bool(compact)), _lib.stream_ptr())
     if ev:
         ev[1].record()
     _lib.check(rc, "rac_sampling4d_fwd")

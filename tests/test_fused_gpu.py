@@ -58,6 +58,70 @@ def test_sampling4d_fused(cfg):
     assert err_u.median().item() < 1e-4 and (err_u > 5e-4).float().mean().item() < 1e-3
 
 
+@pytest.mark.parametrize("cfg", [syn.SMALL6, syn.F8, syn.F8_3CAM], ids=["small6", "f8", "f8_3cam"])
+def test_sampling4d_variants_agree_and_follow_the_rigs_coverage(cfg):
+    """The kernel's two variants (points without any tap set aside / plain) give the same bits on every rig, and the decoder
+    picks between them from the rig's measured coverage, not from the number of cameras: a 6-camera rig with three failed
+    cameras (zero projection matrices) is treated like the 3-camera rig."""
+    from racformer_amd.fused import sampling4d_fused
+    from racformer_amd.transformer import compact_variant, rig_coverage
+    tr, sd, qb, qf, metas = _setup(cfg, 41, 42)
+    smp = tr.decoder.decoder_layer.sampling
+    feats = [f.to(DEV) for f in R.regroup_pyramid(syn.make_pyramid(cfg, 41), cfg.num_cams)]
+    with torch.no_grad():
+        lin = (smp.sampling_offset(qf.to(DEV)), smp.ray_points_offset(qf.to(DEV)), smp.scale_weights(qf.to(DEV)))
+        outs = [sampling4d_fused(feats, qb.to(DEV), *lin, metas[0]["time_diff"], metas[0]["lidar2img"], cfg.num_frames, cfg.num_groups,
+                                 cfg.num_points, cfg.img_depth_num, list(cfg.pc_range), cfg.d_region_list[1], cfg.image_hw[0],
+                                 cfg.image_hw[1], compact=c) for c in (False, True, None)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    cov = metas[0]["_rac_coverage"]
+    assert compact_variant(cov) == (cfg.num_cams == 3), cov
+    if cfg.num_cams == 6:
+        l2i = np.asarray(syn.make_img_metas(cfg)[0]["lidar2img"]).copy()
+        l2i[[1, 3, 5]] = 0.0
+        assert compact_variant(rig_coverage(l2i, 6, cfg.image_hw, cfg.pc_range)) is True
+
+
+def test_sampling4d_four_samples_per_forward_level0_beyond_2gib():
+    """B = 4 at f8 shapes: level 0 of the grouped pyramid holds 2.2 GB, more than a 31-bit tap offset reaches -- the descriptors
+    are per slot since round 3, so the last sample's slots (beyond 2 GiB) are sampled like the first one's: batch element 3 against
+    the ORACLE's sampling_4d on that element's own maps, and the whole batch against its own elements run one by one."""
+    from dataclasses import replace
+    from racformer_amd.fused import sampling4d_fused
+    cfg = replace(syn.F8, batch=4)
+    one = syn.F8
+    tr, sd, qb1, qf1, metas1 = _setup(one, 51, 52)
+    smp = tr.decoder.decoder_layer.sampling
+    g = torch.Generator().manual_seed(9)
+    qb = qb1.repeat(4, 1, 1)
+    qb[..., 0:2] = (qb[..., 0:2] + 0.013 * torch.arange(4).view(4, 1, 1)) % 1.0
+    qf = qf1.repeat(4, 1, 1) + 0.5 * torch.randn(4, one.num_query, 256, generator=g)
+    S1 = one.num_frames * one.num_groups
+    feats = [torch.randn(4 * S1, one.num_cams, h, w, 64, generator=g).to(DEV) for (h, w) in one.fpn_hw]
+    assert feats[0].numel() * 4 > 2 ** 31
+    td = metas1[0]["time_diff"].repeat(4, 1).contiguous()
+    l2i = metas1[0]["lidar2img"].repeat(4, 1, 1, 1).contiguous()
+    args = (one.num_frames, one.num_groups, one.num_points, one.img_depth_num, list(one.pc_range), one.d_region_list[1], one.image_hw[0],
+            one.image_hw[1])
+    with torch.no_grad():
+        lin = [m(qf.to(DEV)) for m in (smp.sampling_offset, smp.ray_points_offset, smp.scale_weights)]
+        out = sampling4d_fused(feats, qb.to(DEV), *lin, td, l2i, *args)
+        for b in range(4):
+            ob = sampling4d_fused([f[b * S1:(b + 1) * S1] for f in feats], qb[b:b + 1].to(DEV), *[x[b:b + 1].contiguous() for x in lin],
+                                  td[b:b + 1], l2i[b:b + 1], *args)
+            assert torch.equal(out[b:b + 1], ob), b
+        # oracle on the last element
+        b = 3
+        tdc = R.time_diff_from_metas(syn.make_img_metas(one), 1, one.num_cams)
+        l2c = torch.from_numpy(np.asarray([m["lidar2img"] for m in syn.make_img_metas(one)]).astype(np.float32))
+        pts, sw = R.image_keypoints(sd, qb[b:b + 1], qf[b:b + 1], tdc, one.d_region_list[1], one)
+        ref = R.sampling_4d(pts, [f[b * S1:(b + 1) * S1].cpu() for f in feats], sw, l2c, one.image_hw[0], one.image_hw[1])
+    err = (out[b:b + 1].cpu() - ref).abs().reshape(one.num_query, -1).amax(-1)
+    # (white-noise maps: a query one of whose points picked another camera differs by O(1); all others to fp32 rounding)
+    assert err.median().item() < 1e-4 and (err > 1e-3).float().mean().item() < 0.01, (err.median().item(), (err > 1e-3).float().mean().item())
+
+
 @pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])
 def test_bev_sampling_fused(cfg):
     tr, sd, qb, qf, metas = _setup(cfg, 31, 32)

@@ -79,7 +79,7 @@ def test_c_abi_argument_errors_without_gpu():
     pc = (ctypes.c_float * 6)(*syn.PC_RANGE)
     db = (ctypes.c_float * 3)(-0.1, 0.0, 0.1)
     rc = lib.rac_sampling4d_fwd(one, hw, 4, p8, p8, p8, p8, p8, p8, p8, p8, None, None, None, 144, 3, 1536, 1, 8, 6, 4, 900, 4, 3, 32,
-                                pc, db, 0.08, 256.0, 704.0, 1e-5, 0, None)
+                                pc, db, 0.08, 256.0, 704.0, 1e-5, 0, -1, None)
     assert rc == -1 and b"64 channels" in lib.rac_last_error()
     rc = lib.rac_sasa_fwd(p8, p8, p8, None, p8, 776, 8, 1, 900, 8, 16, pc, None)
     assert rc == -1 and b"head dim" in lib.rac_last_error()

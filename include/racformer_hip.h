@@ -127,6 +127,8 @@ int rac_box_prep_fwd(const float *query_bbox, float *table, int num_boxes, const
  *                  choices to take the path's one discontinuous step out of a comparison.  loc_out then still reports
  *                  the kernel's OWN choice in its third component (and the imposed view's u, v).
  *   pc_range (6), depth_base (D = torch.linspace(-d_region,d_region,D)): HOST pointers
+ *   limits       : NP*D <= 128 points per (slot, query); the kernel takes 8 queries per workgroup, fewer where their tap table
+ *                  (queries * NP*D * L * 32 bytes) would exceed 64 KB of LDS (NP*D = 64, L = 4: four); 64 channels per group
  *   compact      : 1 = the variant that sets points without any tap aside (rigs that do not cover the full circle), 0 = plain,
  *                  -1 = decide by the number of cameras (<= 3).  Same results either way. */
 int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox,

@@ -360,11 +360,16 @@ extern "C" int rac_sampling4d_fwd(const void *const *feats, const int32_t *hw, i
     a.d_region = d_region; a.image_h = image_h; a.image_w = image_w; a.eps = eps;
     a.L = L; a.B = B; a.T = T; a.N = N; a.G = G; a.Q = Q; a.NP = NP; a.D = D; a.P = P;
     a.ld_off = ld_off; a.ld_ray = ld_ray; a.ld_scale = ld_scale;
+    // queries per workgroup: S4D_ROWS, fewer where the tap table of that many rows (rows * P * L * 32 bytes) would not fit 64 KB
+    // (P = 64 with four levels: 4 rows; P = 128 with five levels: 2)
     a.rows = S4D_ROWS;
+    auto lds_bytes = [&](int rows) { return ((size_t)rows * P * 8 * L + (size_t)N * 16) * sizeof(float) + 2 * (size_t)rows * P; };
+    while (a.rows > 1 && lds_bytes(a.rows) > 64 * 1024)
+        a.rows >>= 1;
     a.blocks_per_slot = (Q + a.rows - 1) / a.rows;
     const int S = B * T * G;
     const int nb = 8 * ((S + 7) / 8) * a.blocks_per_slot;
-    const size_t lds = ((size_t)a.rows * P * 8 * L + (size_t)N * 16) * sizeof(float) + 2 * (size_t)a.rows * P;
+    const size_t lds = lds_bytes(a.rows);
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_sampling4d_fwd: P=%d x L=%d too large for the LDS tap table", P, L);
     hipStream_t st = (hipStream_t)stream;
     // Rigs whose cameras do not cover the full circle leave many points without any tap; the COMPACT variant walks only the others

@@ -24,7 +24,11 @@ def _setup(cfg, seed, wseed):
     return tr, sd, qb, qf, metas
 
 
-@pytest.mark.parametrize("cfg", [syn.SMALL, syn.SMALL6, syn.F8, syn.F8_3CAM])
+from dataclasses import replace as _replace
+MANY_POINTS = _replace(syn.SMALL6, num_points=16, img_depth_num=4)      # P = 64: the tap table of 8 rows would not fit, 4 do
+
+
+@pytest.mark.parametrize("cfg", [syn.SMALL, syn.SMALL6, syn.F8, syn.F8_3CAM, MANY_POINTS])
 def test_sampling4d_fused(cfg):
     tr, sd, qb, qf, metas = _setup(cfg, 21, 22)
     layer = tr.decoder.decoder_layer
@@ -118,8 +122,9 @@ def test_sampling4d_four_samples_per_forward_level0_beyond_2gib():
         pts, sw = R.image_keypoints(sd, qb[b:b + 1], qf[b:b + 1], tdc, one.d_region_list[1], one)
         ref = R.sampling_4d(pts, [f[b * S1:(b + 1) * S1].cpu() for f in feats], sw, l2c, one.image_hw[0], one.image_hw[1])
     err = (out[b:b + 1].cpu() - ref).abs().reshape(one.num_query, -1).amax(-1)
-    # (white-noise maps: a query one of whose points picked another camera differs by O(1); all others to fp32 rounding)
-    assert err.median().item() < 1e-4 and (err > 1e-3).float().mean().item() < 0.01, (err.median().item(), (err > 1e-3).float().mean().item())
+    # (white-noise maps, O(1) per pixel: an ulp of a pixel coordinate is 1e-5 of a pixel and moves a sum of 16 taps by ~1e-4; a
+    #  query one of whose points picked another camera differs by O(1))
+    assert err.median().item() < 5e-4 and (err > 5e-3).float().mean().item() < 0.01, (err.median().item(), (err > 5e-3).float().mean().item())
 
 
 @pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])

@@ -335,7 +335,6 @@ def main():
         captured = CapturedStep(head, pyramid, lss, radar, metas)
     lanes, turn = [], [0]
     if captured is not None and args.in_flight > 1:
-        main_stream = torch.cuda.current_stream(device)
         lanes = [(captured, torch.cuda.Stream(device=device))]
         lanes += [(CapturedStep(head, pyramid, lss, radar, metas, own_scratch=True), torch.cuda.Stream(device=device))
                   for _ in range(args.in_flight - 1)]
@@ -344,14 +343,13 @@ def main():
         if captured is None:
             return eager_step()
         if lanes:
+            # the lane's stream carries the metas staging, the replay AND the all-gather of its step (the process group orders the
+            # collectives among themselves; a lane never waits for another lane's replay)
             cap, st = lanes[turn[0] % len(lanes)]
             turn[0] += 1
-            st.wait_stream(main_stream)
             with torch.cuda.stream(st):
                 _, det = cap.replay(img_metas=metas)
-            if use_pg:
-                main_stream.wait_stream(st)            # the collective is issued on the main stream
-            return dp.all_gather_detections(det, force_collective=args.force_collective)
+                return dp.all_gather_detections(det, force_collective=args.force_collective)
         _, det = captured.replay(img_metas=metas)
         return dp.all_gather_detections(det, force_collective=args.force_collective)
 

@@ -25,6 +25,9 @@
 typedef _Float16 cv_h8 __attribute__((ext_vector_type(8)));
 typedef float cv_f4 __attribute__((ext_vector_type(4)));
 
+#ifndef CV_TAP_MAJOR
+#define CV_TAP_MAJOR 0
+#endif
 #define CV_TM 256
 #define CV_COUT 256
 #define CV_STAGE_U4 4096 /* uint4 per LDS stage: A 2048 + B 2048 */
@@ -184,12 +187,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
     const size_t a_base0 = row_base(0), a_base1 = row_base(1), a_base2 = row_base(2), a_base3 = row_base(3);
     const int st0 = row_slot(0), st1 = row_slot(1), st2 = row_slot(2), st3 = row_slot(3);
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    // K order: chunk-major, the 9 taps of a 32-channel chunk back to back -- they re-read the same 4 image rows of that chunk
+    // (66 KB per workgroup, 2 MB per XCD: L2 hits), where tap-major had 10 chunks = 320 KB per workgroup between two reads of a
+    // line (10 MB per XCD > the 4 MB L2: every tap came from the Infinity Cache -- PMC 1.62 GB fetched per launch for a 173 MB
+    // image).  CV_TAP_MAJOR = 1: the old order (A/B builds).
 #define CV_GLOAD(ks_)                                                                          \
     do {                                                                                       \
-        const int tap_ = (ks_) / chunks, chunk_ = (ks_) - tap_ * chunks;                       \
+        const int chunk_ = CV_TAP_MAJOR ? (ks_) % chunks : (ks_) / 9;                          \
+        const int tap_ = CV_TAP_MAJOR ? (ks_) / chunks : (ks_) - chunk_ * 9;                   \
         const int dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;                                        \
         const size_t off_ = ((size_t)dy_ * Wp + dx_) * pix_stride + (size_t)chunk_ * 8;        \
-        const uint4 *wsrc_ = a.ws + (size_t)(ks_) * 2048 + tid;                                \
+        const uint4 *wsrc_ = a.ws + (size_t)(tap_ * chunks + chunk_) * 2048 + tid;             \
         ra0 = a.xs[a_base0 + off_]; ra1 = a.xs[a_base1 + off_];                            \
         ra2 = a.xs[a_base2 + off_]; ra3 = a.xs[a_base3 + off_];                            \
         rb0 = wsrc_[0]; rb1 = wsrc_[512]; rb2 = wsrc_[1024]; rb3 = wsrc_[1536];        \
@@ -343,15 +351,17 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv3x3s2_c64_f16x3_kernel(cons
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define S2_GLOAD(ks_)                                                                          \
     do {                                                                                       \
-        const int tap_ = (ks_) / chunks, chunk_ = (ks_) - tap_ * chunks;                       \
+        const int chunk_ = CV_TAP_MAJOR ? (ks_) % chunks : (ks_) / 9;                          \
+        const int tap_ = CV_TAP_MAJOR ? (ks_) / chunks : (ks_) - chunk_ * 9;  /* chunk-major, as above */ \
         const int dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;                                        \
         const size_t off_ = ((size_t)dy_ * Wp + dx_) * pix_stride + (size_t)chunk_ * 8;        \
+        const size_t wk_ = (size_t)(tap_ * chunks + chunk_) * 512;                             \
         ra0 = a.xs[a_base0 + off_]; ra1 = a.xs[a_base1 + off_];                                \
         ra2 = a.xs[a_base2 + off_]; ra3 = a.xs[a_base3 + off_];                                \
-        rb0 = a.ws[(size_t)(ks_) * 512 + tid]; rb1 = a.ws[(size_t)(ks_) * 512 + S2_THREADS + tid];   \
+        rb0 = a.ws[wk_ + tid]; rb1 = a.ws[wk_ + S2_THREADS + tid];                             \
         if (S2_NB > 2) {                                                                       \
-            rb2 = a.ws[(size_t)(ks_) * 512 + 2 * S2_THREADS + tid];                            \
-            rb3 = a.ws[(size_t)(ks_) * 512 + 3 * S2_THREADS + tid];                            \
+            rb2 = a.ws[wk_ + 2 * S2_THREADS + tid];                                            \
+            rb3 = a.ws[wk_ + 3 * S2_THREADS + tid];                                            \
         }                                                                                      \
     } while (0)
 #define S2_LSTORE(buf_)                                                                        \

@@ -49,7 +49,7 @@ TAIL_QUERIES = (0, 0, 0, 2, 3, 10)                    # random-everything rig, p
 TAIL_BUDGET = tuple(q / 900.0 for q in TAIL_QUERIES)  # ... as a fraction of the queries
 TAIL_TOL = 2e-2                                       # ... and by how much at most (box space; measured maximum 9.9e-3)
 ARGMAX_MARGIN = (4.8e-6, 2.7e-5, 8.8e-5, 2.3e-4, 3.9e-3, 1.2e-2)   # measured CPU-vs-CPU logit drift per layer (see above)
-MAX_FLIPPED_POINTS = 6                                # differing camera choices per forward on the equalised trajectory
+MAX_FLIPPED_POINTS = 7                                # differing camera choices per forward on the equalised trajectory
                                                       # (of ~2.07 M points at f8; measured maximum + 1)
 USED = []                                             # one record per comparison: what of the allowances it actually used
 

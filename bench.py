@@ -326,13 +326,17 @@ def main():
             det = head.get_detections_fixed(preds)          # [1,300,11]
             return dp.all_gather_detections(det, force_collective=args.force_collective)   # [world,1,300,11]
 
-    captured = None
+    captured, capture_error = None, None
     if not args.no_graph:
         # the whole step (regroup + prologue + 6 layers + decode) as ONE HIP-graph submission; per step the host stages the
         # sample's metas (timestamps -> time_diff, lidar2img: the float64 host arithmetic of racformer_transformer.py:99-109)
         # in front of the replay and issues the all-gather behind it
         from racformer_amd.graph import CapturedStep
-        captured = CapturedStep(head, pyramid, lss, radar, metas)
+        try:
+            captured = CapturedStep(head, pyramid, lss, radar, metas)
+        except Exception as e:       # (a box whose runtime refuses the capture still gets a measured, eager number -- and says so)
+            capture_error = f"{type(e).__name__}: {e}"[:300]
+            torch.cuda.synchronize()
     lanes, turn = [], [0]
     if captured is not None and args.in_flight > 1:
         lanes = [(captured, torch.cuda.Stream(device=device))]
@@ -475,7 +479,8 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "per_rank_ms_per_step": per_rank_ms,
         # host-side time to enqueue one step (Python + launches, rank 0): close to ms_per_step means the host is the limiter
         "host_enqueue_ms_per_step": 1e3 * host_elapsed / args.steps,
-        "submission": "eager: one launch per kernel from Python" if captured is None else
+        "submission": ("eager: one launch per kernel from Python" + (f" (graph capture failed: {capture_error})" if not args.no_graph and capture_error else ""))
+                      if captured is None else
                       "HIP graph: the step's kernels captured once (racformer_amd/graph.py), one replay per step; metas staged in "
                       "front of it, all-gather behind it" + (f"; {len(lanes)} plans on streams of their own, replayed round-robin, so "
                       "that up to that many samples are in flight per GPU (the latency-bound launches of one sample run beside the "

@@ -36,7 +36,8 @@ def test_bench_rank_refuses_world_size_mismatch():
 
 
 def test_bench_parent_reports_child_failure():
-    # an unknown flag makes every child exit non-zero inside torch.distributed.run; the parent must pass that on
+    # RAC_BENCH_TEST_FAIL makes the last rank exit non-zero inside torch.distributed.run (bench.py: plumbing_only); the parent
+    # started by `--gpus 2` must pass that status on
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing-only", "--blas", "x", "--steps", "-1", "--config", "f8",
                         "--warmup", "0"], env=dict(_env(), RAC_BENCH_TEST_FAIL="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0

@@ -135,12 +135,15 @@ __global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(con
         }
     }
     __syncthreads();
+    // (the slot index through readfirstlane: the descriptor base then is scalar arithmetic -- left to itself hipcc computes it in
+    //  vector registers and wraps every buffer load in a waterfall loop over a descriptor it can no longer prove uniform: +6 us)
+    const int s_uni = __builtin_amdgcn_readfirstlane(s);
     __amdgpu_buffer_rsrc_t rsrc[L];
 #pragma unroll
     for (int l = 0; l < L; ++l)
         // (one descriptor per level over THIS SLOT's N maps: offsets are relative to the slot, so only a slot's bytes -- not the whole
         //  level's, B * T * G slots -- have to stay below the 31-bit tap offsets)
-        rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.feat[l]) + (size_t)s * a.feat_bytes[l]), 0,
+        rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.feat[l]) + (size_t)s_uni * a.feat_bytes[l]), 0,
                                                     a.feat_bytes[l], 0x00020000);
     const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
     // wave w gathers rows w, w+4 of the workgroup; per tap: one add for the lane's channel offset, one buffer load, two

@@ -266,7 +266,7 @@ def main():
                     help="feed the pyramid already in the sampling layout (producer-side layout, row f2): no regroup")
     ap.add_argument("--no-graph", action="store_true",
                     help="time the eager plan (one Python-issued launch per kernel) instead of the captured HIP graph")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="samples in flight per GPU: that many captured plans on streams of their own, replayed round-robin "
                          "(the latency-bound launches of one sample run beside the bandwidth-bound ones of the other)")
     ap.add_argument("--force-collective", action="store_true",

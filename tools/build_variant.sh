@@ -18,7 +18,7 @@ for o in $src/*.o; do
 done
 for f in "$@"; do
   b=$(basename $f .hip)
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $flags -c $src/$b.hip -o $out/$b.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops $flags -c $src/$b.hip -o $out/$b.o
   objs="$objs $out/$b.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build/lib_$name.so $objs

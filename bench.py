@@ -545,6 +545,7 @@ def main():
                 "value": args.steps / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / args.steps,
                 "note": "secondary figure: pyramid handed over as [B*T*G,N,H,W,C] (producer-side layout, SURVEY 8 row f2), no "
                         "regroup in the step; the headline `value` times the reference layout WITH the regroup"}
+            cap2.close()
             del cap2
         finally:
             dec.pregrouped = False

@@ -417,6 +417,12 @@ class scratch_namespace:
         _scratch_ns[0] = self.prev
 
 
+def release_scratch(key):
+    """Drops the scratch buffers of a namespace (a captured plan that owned them is gone)."""
+    for k in [k for k in _conv_images if k[-1] == key]:
+        del _conv_images[k]
+
+
 class ConvImage:
     """The padded channel-last f16 hi/lo activation image of the convolution kernels, filled in stages:
     ``begin`` (absmax -> the activations' power-of-two scale), ``pack`` (NCHW fp32 source -> a channel range), then

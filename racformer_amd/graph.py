@@ -73,10 +73,19 @@ class CapturedStep:
 
         from .fused import scratch_namespace
         CapturedStep._serial[0] += 1
-        with scratch_namespace(("captured_step", CapturedStep._serial[0]) if own_scratch else None):
+        self._scratch_key = ("captured_step", CapturedStep._serial[0]) if own_scratch else None
+        with scratch_namespace(self._scratch_key):
             self._cap = CapturedForward(run, self.device, warmup)
         self.graph = self._cap.graph
         self.preds, self.det = self._cap.outputs
+
+    def close(self):
+        """Releases the graph and, if the plan owned scratch buffers, those (they are otherwise kept for reuse by later forwards)."""
+        from .fused import release_scratch
+        self._cap = self.graph = self.preds = self.det = None
+        if self._scratch_key is not None:
+            release_scratch(self._scratch_key)
+            self._scratch_key = None
 
     def _stage(self, img_metas):
         """time_diff / time_diff_safe / lidar2img of a new sample into the device block the captured kernels read."""

@@ -95,3 +95,28 @@ def test_rig_coverage_selects_the_sampling_kernel_variant():
     failed = np.asarray(syn.make_img_metas(syn.F8)[0]["lidar2img"]).copy()
     failed[[0, 2, 4]] = 0.0                                    # three of the six cameras deliver nothing
     assert compact_variant(rig_coverage(failed, 6, syn.F8.image_hw, syn.F8.pc_range)) is True
+
+
+def test_scratch_namespaces_and_fpn_writer_contract():
+    """Host logic of round 3's additions: scratch namespaces nest and restore (plans in flight own their buffers), the FPN
+    output writer carries mmdet's FPN.fpn_convs state-dict keys, and both refuse host tensors (no CPU fallback)."""
+    from racformer_amd import fused
+    from racformer_amd.fpn_writer import FPNOutputWriter
+    assert fused._scratch_ns[0] is None
+    with fused.scratch_namespace("a"):
+        assert fused._scratch_ns[0] == "a"
+        with fused.scratch_namespace(("b", 1)):
+            assert fused._scratch_ns[0] == ("b", 1)
+        assert fused._scratch_ns[0] == "a"
+    assert fused._scratch_ns[0] is None
+    fused._conv_images[(1, 2, 3, 32, "cpu", "gone")] = object()
+    fused.release_scratch("gone")
+    assert not any(k[-1] == "gone" for k in fused._conv_images)
+    wr = FPNOutputWriter(num_levels=4, num_cams=6)
+    keys = set(wr.state_dict())
+    assert keys == {f"fpn_convs.{i}.conv.{n}" for i in range(4) for n in ("weight", "bias")}
+    assert tuple(wr.fpn_convs[0].conv.weight.shape) == (256, 256, 3, 3) and wr.fpn_convs[0].conv.padding == (1, 1)
+    with pytest.raises(RuntimeError, match="CUDA tensor|no CPU fallback|HIP library"):
+        wr([torch.zeros(6, 256, 4, 8)])
+    with pytest.raises(ValueError):
+        FPNOutputWriter(channels=128)

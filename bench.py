@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4,
                     help="samples in flight per GPU: that many captured plans on streams of their own, replayed round-robin "
                          "(the latency-bound launches of one sample run beside the bandwidth-bound ones of the other)")
+    ap.add_argument("--same-inputs-per-lane", action="store_true",
+                    help="A/B switch: every lane replays lane 0's input buffers (round 3's arrangement) instead of a sample of its own")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the RCCL process group and issue the all-gather even in a world of one rank "
                          "(single-GPU rehearsal of the N > 1 path)")
@@ -310,10 +312,18 @@ def main():
         print(json.dumps({"roofline_stress": stress_block(cfg, device)}))
         return
     head = build_head(cfg, device, fdt)
-    seed = rank  # every rank decodes its own sample
-    pyramid = [f.to(device) for f in syn.make_pyramid(cfg, seed)]
-    lss, radar = syn.make_bev(cfg, seed, 0).to(device), syn.make_bev(cfg, seed, 1).to(device)
-    metas = syn.make_img_metas(cfg)
+    n_lanes = max(1, args.in_flight) if not args.no_graph else 1
+
+    def sample_inputs(seed):
+        """One synthetic nuScenes-shaped sample, resident in HBM: pyramid, the two BEV stacks and metas of its own."""
+        return ([f.to(device) for f in syn.make_pyramid(cfg, seed)], syn.make_bev(cfg, seed, 0).to(device),
+                syn.make_bev(cfg, seed, 1).to(device), syn.make_img_metas(cfg, sample=seed))
+
+    # every rank decodes samples of its own, and every lane of a rank (samples in flight) a DIFFERENT one: sample index
+    # rank * lanes + lane, as a sampler that deals consecutive samples to the lanes would (val.py:105-114,133-136 evaluates distinct
+    # samples one after another); lane 0 of rank 0 is sample 0
+    seed = rank * n_lanes
+    pyramid, lss, radar, metas = sample_inputs(seed)
     if args.pregrouped:
         from racformer_amd.transformer import regroup_pyramid
         pyramid = regroup_pyramid(pyramid, cfg.num_cams, 4, fdt)
@@ -338,10 +348,16 @@ def main():
             capture_error = f"{type(e).__name__}: {e}"[:300]
             torch.cuda.synchronize()
     lanes, turn = [], [0]
+    lane_inputs = [(pyramid, lss, radar, metas)]
     if captured is not None and args.in_flight > 1:
-        lanes = [(captured, torch.cuda.Stream(device=device))]
-        lanes += [(CapturedStep(head, pyramid, lss, radar, metas, own_scratch=True), torch.cuda.Stream(device=device))
-                  for _ in range(args.in_flight - 1)]
+        lanes = [(captured, torch.cuda.Stream(device=device), metas)]
+        for i in range(1, args.in_flight):
+            if args.same_inputs_per_lane:        # (round 3's arrangement, kept as an A/B switch: every lane reads lane 0's buffers)
+                lane_inputs.append(lane_inputs[0])
+            else:
+                lane_inputs.append(sample_inputs(seed + i))
+            p_i, l_i, r_i, m_i = lane_inputs[-1]
+            lanes.append((CapturedStep(head, p_i, l_i, r_i, m_i, own_scratch=True), torch.cuda.Stream(device=device), m_i))
 
     def step():
         if captured is None:
@@ -349,10 +365,10 @@ def main():
         if lanes:
             # the lane's stream carries the metas staging, the replay AND the all-gather of its step (the process group orders the
             # collectives among themselves; a lane never waits for another lane's replay)
-            cap, st = lanes[turn[0] % len(lanes)]
+            cap, st, m_i = lanes[turn[0] % len(lanes)]
             turn[0] += 1
             with torch.cuda.stream(st):
-                _, det = cap.replay(img_metas=metas)
+                _, det = cap.replay(img_metas=m_i)
                 return dp.all_gather_detections(det, force_collective=args.force_collective)
         _, det = captured.replay(img_metas=metas)
         return dp.all_gather_detections(det, force_collective=args.force_collective)
@@ -378,12 +394,18 @@ def main():
     host_elapsed = time.perf_counter() - t0     # the host has enqueued every step (it runs ahead of the GPU unless it is the limiter)
     fence()
     elapsed = time.perf_counter() - t0
-    single = lanes_agree = None
+    single = lanes_match = None
     if captured is not None:
         if lanes:
-            # the lanes ran the same sample: their detections must be the same bits (a cross-plan race would show here) ...
-            ref_det = lanes[0][0].det
-            lanes_agree = all(bool(torch.equal(cap.det, ref_det)) for cap, _ in lanes)
+            # every lane ran a sample of its own beside the others: what its last replay left must be, bit for bit, what ONE plan
+            # alone produces on that lane's sample -- the eager step (one launch per kernel, nothing else on the GPU), computed here,
+            # outside the timed region (a cross-plan race or a lane reading another lane's buffers would show here) ...
+            lanes_match = []
+            for (cap, _, m_i), (p_i, l_i, r_i, _) in zip(lanes, lane_inputs):
+                with torch.no_grad():
+                    alone = head.get_detections_fixed(head(list(p_i), l_i, r_i, [dict(m) for m in m_i]))
+                torch.cuda.synchronize()
+                lanes_match.append(bool(torch.equal(cap.det, alone)))
             # ... and the same K steps with ONE plan in flight: the latency-bound figure beside the throughput one
             t1 = time.perf_counter()
             for _ in range(args.steps):
@@ -486,7 +508,9 @@ def main():
                       "that up to that many samples are in flight per GPU (the latency-bound launches of one sample run beside the "
                       "bandwidth-bound ones of another)" if lanes else ""),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "collective": collective,
-        "one_sample_in_flight": single, "lanes_agree_bitwise": lanes_agree,
+        "one_sample_in_flight": single,
+        # per lane: detections of the lane's last replay (run beside the other lanes) == the single-plan eager result on that lane's sample
+        "lanes_match_single_plan_bitwise": lanes_match,
         "dtype": "f32" if fdt == torch.float32 else "bf16-features/f32-math", "data": "synthetic",
         "arithmetic_note": "fp32 storage and fp32-accurate results throughout; the largest contractions run on the 16-bit "
                            "matrix cores as split-precision products (operands = sums of f16/bf16 terms, fp32 accumulate, "
@@ -495,6 +519,9 @@ def main():
                                "layers + NMS-free decode, 1 sample/GPU/step",
                    "queries": cfg.num_query, "cams": cfg.num_cams, "frames": cfg.num_frames,
                    "levels": cfg.num_levels, "samples_per_gpu": 1, "samples_in_flight_per_gpu": max(1, args.in_flight if captured is not None else 1),
+                   # each lane holds a sample of its own (pyramid, BEV stacks, metas: synthetic seeds rank * lanes + lane)
+                   "distinct_inputs_per_lane": bool(lanes) and not args.same_inputs_per_lane,
+                   "sample_seeds_this_rank": [seed + i for i in range(len(lanes) or 1)] if not args.same_inputs_per_lane else [seed],
                    "parallelism": f"dp{world}",
                    "pyramid_layout": "pregrouped [B*T*G,N,H,W,C]" if args.pregrouped else "reference [B,T*N,G*C,H,W] (regroup timed)"},
         "roofline": {"bound": "hbm", "kernel": "sampling4d_c64_kernel (rac_sampling4d_fwd: keypoints + projection + view select + gather)",
@@ -566,7 +593,7 @@ def main():
                 if i == warm + reps - 1:
                     R.LOC_TAP = []
                 c0 = time.perf_counter()
-                ref = R.head_forward(hsd, sd, cpu_pyr, lss.cpu(), radar.cpu(), syn.make_img_metas(cfg), cfg)
+                ref = R.head_forward(hsd, sd, cpu_pyr, lss.cpu(), radar.cpu(), syn.make_img_metas(cfg, sample=seed), cfg)
                 times.append(time.perf_counter() - c0)
         oviews = torch.stack([R.views_of(l, cfg.num_cams) for l in R.LOC_TAP])
         R.LOC_TAP = None
@@ -598,11 +625,18 @@ def main():
             "note": "free-running six layers with each side's own camera choices (tests/parity.py explains the criterion the "
                     "tests apply: differing choices equalised, per-layer tail budget)"}
 
+    bad_lanes = lanes_match is not None and not all(lanes_match)
+    if bad_lanes:
+        # a lane that does not reproduce the single-plan result is a wrong result, not a throughput: no headline number
+        result["invalid"] = f"lanes_match_single_plan_bitwise = {lanes_match}: value withheld (was {result['value']:.2f})"
+        result["value"] = None
     if rank == 0:
         print(json.dumps(result))
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+    if bad_lanes:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

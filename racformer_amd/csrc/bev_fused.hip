@@ -98,6 +98,20 @@ __device__ __forceinline__ void bev_keypoint(const BevArgs &a, const BevStream &
 #define BEV_TS 4   /* point subsets per item: 16-lane group (k, ts) handles points ts, ts+4, ... of every frame */
 #define BEV_TAP_OUTSIDE 0x80000000u   /* tap offset past the end of the value buffer: the buffer load returns zeros */
 
+// Diagnostic build only (tools/bev_phase_split.py; -DBEV_STAMPS): s_memtime at the phase boundaries of every workgroup (wave 0),
+// kept in a device array of the code object and read back through rac_dbg_bev_stamps.  Not part of the product library or its ABI.
+#ifdef BEV_STAMPS
+#define BEV_STAMP_WGS 4096
+__device__ unsigned long long bev_stamp_buf[BEV_STAMP_WGS * 8];
+#define BEV_STAMP(i)                                                                                    \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < BEV_STAMP_WGS)                    \
+            bev_stamp_buf[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define BEV_STAMP(i)
+#endif
+
 typedef float bev_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int bev_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int bev_u4 __attribute__((ext_vector_type(4)));
@@ -150,6 +164,7 @@ template <typename FT>
 __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const BevArgs a)
 {
     extern __shared__ float smem[];
+    BEV_STAMP(0);
     const BevStream &s = a.s[blockIdx.y];
     const int tid = threadIdx.x;
     const int c4 = tid & 15, grp = tid >> 4;
@@ -252,6 +267,7 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
         }
     }
     __syncthreads();
+    BEV_STAMP(1);
     // phase B: per-frame keypoints
     const int H = a.H, W = a.W;
     const unsigned pix_bytes = (unsigned)(a.heads * 64 * sizeof(FT));   // one pixel: heads x 64 channels
@@ -307,6 +323,7 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
         }
     }
     __syncthreads();
+    BEV_STAMP(2);
 
     // phase C: a group walks its list (frame-major: the chip works on (nearly) one frame at a time, which the L2s /
     // Infinity Cache hold better than all of them), BEV_U keypoints = 4 * BEV_U taps in flight.  Per tap: one add for
@@ -340,6 +357,7 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
     }
     rac_f4 acc;
     rac_acc4_get(acc4, acc.x, acc.y, acc.z, acc.w);
+    BEV_STAMP(3);
     // phase D: fixed-order sum of the four point subsets (deterministic, no atomics)
     *reinterpret_cast<rac_f4 *>(spart + (k * BEV_TS + ts) * 64 + c4 * 4) = acc;
     __syncthreads();
@@ -352,7 +370,27 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
         }
         *reinterpret_cast<rac_f4 *>(s.out + ((size_t)b * per_b + (i0 + k)) * 64 + c4 * 4) = o;
     }
+    BEV_STAMP(4);
+#ifdef BEV_STAMPS
+    if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < BEV_STAMP_WGS) {
+        // where the workgroup ran: HW_ID (gfx9: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13) and the XCC id register
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        bev_stamp_buf[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
+
+#ifdef BEV_STAMPS
+extern "C" int rac_dbg_bev_stamps(unsigned long long *host_out, int n_wgs)
+{
+    if (n_wgs > BEV_STAMP_WGS)
+        n_wgs = BEV_STAMP_WGS;
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bev_stamp_buf), sizeof(unsigned long long) * 8 * n_wgs, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 static int bev_launch(int nstreams, const void *const *values, const float *const *offsets, const float *const *ray_logits,
                       const float *const *scale_logits, const float *const *queue_logits, float *const *outs, float *const *loc_outs,

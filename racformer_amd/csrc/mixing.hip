@@ -307,6 +307,9 @@ __device__ __forceinline__ void mix_split_bf16(float v, __bf16 &t1, __bf16 &t2, 
     t3 = (__bf16)(r1 - (float)t2);
 }
 
+#ifndef RAC_MIX_REVERSE
+#define RAC_MIX_REVERSE 0   /* 1: walk the (query, group) items from the last one (A/B switch) */
+#endif
 #define MIXH_XS 80    /* f16 row stride of the x images  (160 B) */
 #define MIXH_SS 104   /* f16 row stride of the S images  (208 B) */
 #define MIXH_X_BYTES (3 * MIX_PMAX * MIXH_XS * 2)   /* three bf16 terms: 46080 */
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256, 3) void mixing_c64_f16x3_kernel(const MixArgs 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int P = a.P;
-    const int item = blockIdx.x;
+    const int item = RAC_MIX_REVERSE ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int q = item / a.G, g = item % a.G;
     const float *gx = a.x + ((size_t)q * a.G + g) * P * MIX_C;
     const float *gM = a.params + (size_t)q * a.ld_params + (size_t)g * (MIX_C * MIX_C + MIX_OUT * P);

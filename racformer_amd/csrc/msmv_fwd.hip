@@ -178,6 +178,9 @@ __global__ __launch_bounds__(256, (L <= 4 ? 4 : 3)) void msmv_fwd_c64_kernel(con
                     v[l][3] = msmv_tap<FT, 0>(rsrc[l], o.w + lane_off);
                 }
             }
+#if defined(RAC_DIAGNOSTIC_BUILD) && defined(RAC_GATHER_LOADS_FIRST)
+            __builtin_amdgcn_sched_barrier(0);   // diagnostic (tools/race_victims.py): every tap load is issued before the first FMA
+#endif
             rac_acc4 acc4 = rac_acc4_zero();
 #pragma unroll
             for (int l = 0; l < L; ++l) {

@@ -66,8 +66,13 @@ __device__ __forceinline__ rac_f4 rac_ld4(const unsigned short *p)
 // rac_msmv_fwd beside a looping mixing kernel, 110 of 120 launches deviating with v_pk_fma_f32, 0 of 120 with v_fma_f32; same
 // loads, same waits, plain global loads instead of buffer loads made no difference).  Same rounding either way (IEEE fma per
 // component), so results are bit-identical to round 2's.
+// The packed form exists for diagnostic builds only (tools/build_variant.sh defines RAC_DIAGNOSTIC_BUILD; tools/race_victims.py
+// runs them): a product build that asks for it does not compile.
 #ifndef RAC_GATHER_PACKED_FMA
 #define RAC_GATHER_PACKED_FMA 0
+#endif
+#if RAC_GATHER_PACKED_FMA && !defined(RAC_DIAGNOSTIC_BUILD)
+#error "RAC_GATHER_PACKED_FMA is a diagnostic switch (DESIGN 3.12): packed FP32 accumulation goes wrong beside another stream's MFMA kernels"
 #endif
 typedef float rac_f2v __attribute__((ext_vector_type(2)));
 struct rac_acc4 {

@@ -108,16 +108,26 @@ def ring_lidar2img(num_frames, num_cams, image_hw=(256, 704), three_cam_front=Fa
     return [m.copy() for _ in range(num_frames) for m in mats]
 
 
-def make_img_metas(cfg: RigConfig):
+def make_img_metas(cfg: RigConfig, sample=0):
     """One meta dict per sample with the three fields the decoder consumes
-    (racformer_transformer.py:99,107,367)."""
+    (racformer_transformer.py:99,107,367).  ``sample`` > 0: another nuScenes-shaped sample -- the ego frame yawed by
+    0.07 rad per sample index (lidar2img right-multiplied by the rotation) and another frame spacing / time origin, so that
+    time_diff and every projection matrix differ from sample 0's (samples in flight per GPU carry metas of their own)."""
     T, N = cfg.num_frames, cfg.num_cams
+    l2i = ring_lidar2img(T, N, cfg.image_hw, cfg.three_cam_front)
+    dt, t0 = 0.5, 10.0
+    if sample:
+        yaw = 0.07 * sample
+        c, s = np.cos(yaw), np.sin(yaw)
+        ego = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+        l2i = [m @ ego for m in l2i]
+        dt, t0 = 0.5 + 0.01 * (sample % 7), 10.0 + 0.25 * sample
     metas = []
     for b in range(cfg.batch):
-        ts = [10.0 - 0.5 * t + 0.001 * n + 0.01 * b for t in range(T) for n in range(N)]
+        ts = [t0 - dt * t + 0.001 * n + 0.01 * b for t in range(T) for n in range(N)]
         metas.append(dict(
             img_timestamp=ts,
-            lidar2img=ring_lidar2img(T, N, cfg.image_hw, cfg.three_cam_front),
+            lidar2img=[m.copy() for m in l2i],
             img_shape=[(cfg.image_hw[0], cfg.image_hw[1], 3)] * (T * N),
         ))
     return metas

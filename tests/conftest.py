@@ -31,8 +31,10 @@ def _build_oracle_clib():
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """What the parity comparisons of this session actually used of their allowances (tests/parity.py ``USED``): written
-    next to the other GPU-box outputs; the committed copy lives under profiles/."""
+    """What the parity comparisons of this session actually used of their allowances (tests/parity.py ``USED``), written
+    next to the other GPU-box outputs and keyed by the kind of session: ``parity_budget_used_gpu.json`` when a GPU took part
+    (the ``-m gpu`` run), ``parity_budget_used_cpu.json`` otherwise (oracle-vs-golden comparisons here in the container) -- a CPU
+    session can no longer overwrite the GPU session's record.  The committed copy of the GPU record lives under profiles/."""
     import json
     try:
         import parity
@@ -40,12 +42,19 @@ def pytest_sessionfinish(session, exitstatus):
         return
     if not parity.USED:
         return
-    path = os.environ.get("RAC_PARITY_LOG") or os.path.join(ROOT, "gpurun_out", "parity_budget_used.json")
+    try:
+        import torch
+        kind = "gpu" if torch.cuda.is_available() else "cpu"
+    except Exception:
+        kind = "cpu"
+    path = os.environ.get("RAC_PARITY_LOG") or os.path.join(ROOT, "gpurun_out", f"parity_budget_used_{kind}.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "w") as f:
-            json.dump(dict(criteria=dict(tail_queries=parity.TAIL_QUERIES, tail_tol=parity.TAIL_TOL,
-                                         argmax_margin=parity.ARGMAX_MARGIN, max_flipped_points=parity.MAX_FLIPPED_POINTS),
+            json.dump(dict(session=kind, exitstatus=int(exitstatus),
+                           criteria=dict(tail_queries=parity.TAIL_QUERIES, tail_tol=parity.TAIL_TOL,
+                                         argmax_margin=parity.ARGMAX_MARGIN, argmax_margin_init_rig=parity.ARGMAX_MARGIN_INIT_RIG,
+                                         max_flipped_points=parity.MAX_FLIPPED_POINTS),
                            comparisons=parity.USED), f, indent=1)
     except OSError:
         pass

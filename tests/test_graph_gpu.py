@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import restate as R
-from parity import MAX_FLIPPED_POINTS, decoder_parity, detections_parity, fill_rig_module, flipped_points, head_boxes_normalised, kept_rows
+from parity import ARGMAX_MARGIN_INIT_RIG, MAX_FLIPPED_POINTS, decoder_parity, detections_parity, fill_rig_module, flipped_points, head_boxes_normalised, kept_rows
 from racformer_amd import synthetic as syn
 from racformer_amd.graph import CapturedForward, CapturedStep
 from racformer_amd.transformer import RaCFormerTransformer
@@ -52,7 +52,7 @@ def test_captured_decoder_vs_reference(golden_dir, name, cfg, literal):
     nflip = flipped_points(views, g["views"])
     print(name, "captured plan: own camera choices differing from the reference's, per layer:", nflip)
     assert sum(nflip) <= MAX_FLIPPED_POINTS
-    decoder_parity(cls.cpu(), box.cpu(), g["cls"], g["box"], what=name + " (captured)", **(dict(tail_budget=None) if literal else {}))
+    decoder_parity(cls.cpu(), box.cpu(), g["cls"], g["box"], what=name + " (captured)", **(dict(tail_budget=None, argmax_margin=ARGMAX_MARGIN_INIT_RIG) if literal else {}))
 
 
 def test_captured_step_new_metas_and_detections(golden_dir):
@@ -102,36 +102,48 @@ def test_captured_step_new_metas_and_detections(golden_dir):
 
 
 def test_plans_in_flight_side_by_side_match_the_single_plan(golden_dir):
-    """Several samples in flight (bench.py --in-flight N): captured plans with scratch of their own replayed on streams of
-    their own, interleaved and overlapping, each reproduce the single plan's outputs bit for bit (a shared scratch buffer or
-    any other cross-plan state would show here)."""
+    """Several samples in flight (bench.py --in-flight N): captured plans with scratch AND INPUTS of their own -- every lane holds
+    a different sample: pyramid, BEV stacks, metas (round 4; round 3's lanes all read one sample's buffers) -- replayed on streams
+    of their own, interleaved and overlapping.  Each lane reproduces, bit for bit, what ONE plan alone computes on that lane's
+    sample: the eager step with nothing else on the GPU (a shared scratch buffer, a lane reading another lane's inputs or any
+    other cross-plan state would show here)."""
     from test_parity_gpu import build_head
     cfg = syn.F8
     g = np.load(os.path.join(golden_dir, "head_f8.npz"))
     seed, wseed = int(g["seed"]), int(g["weight_seed"])
     head = build_head(cfg, g, seed, wseed)
-    feats = [f.to(DEV) for f in syn.make_pyramid(cfg, seed)]
-    lss, radar = syn.make_bev(cfg, seed, 0).to(DEV), syn.make_bev(cfg, seed, 1).to(DEV)
-    metas = syn.make_img_metas(cfg)
-    other = [dict(m) for m in metas]
-    for m in other:
-        m["img_timestamp"] = [10.0 - 0.4 * (i // cfg.num_cams) + 0.001 * (i % cfg.num_cams) for i in range(len(m["img_timestamp"]))]
-    single = CapturedStep(head, feats, lss, radar, metas)
+    n_lanes = 3
+    samples = []
+    for i in range(n_lanes):
+        feats = [f.to(DEV) for f in syn.make_pyramid(cfg, seed + i)]
+        lss, radar = syn.make_bev(cfg, seed + i, 0).to(DEV), syn.make_bev(cfg, seed + i, 1).to(DEV)
+        metas = syn.make_img_metas(cfg, sample=i)
+        other = syn.make_img_metas(cfg, sample=i + n_lanes)         # a second set of metas for the same buffers (restaged per replay)
+        samples.append((feats, lss, radar, (metas, other)))
     want = []
-    for ms in (metas, other):
-        p, d = single.replay(img_metas=ms)
-        torch.cuda.synchronize()
-        want.append((p["all_bbox_preds"].clone(), d.clone()))
-    assert not torch.equal(want[0][0], want[1][0])
-    lanes = [(CapturedStep(head, feats, lss, radar, metas, own_scratch=True), torch.cuda.Stream()) for _ in range(3)]
+    with torch.no_grad():
+        for feats, lss, radar, both in samples:
+            row = []
+            for ms in both:
+                p = head(list(feats), lss, radar, [dict(m) for m in ms])
+                d = head.get_detections_fixed(p)
+                torch.cuda.synchronize()
+                row.append((p["all_bbox_preds"].clone(), d.clone()))
+            assert not torch.equal(row[0][0], row[1][0])
+            want.append(row)
+    assert not torch.equal(want[0][0][0], want[1][0][0]) and not torch.equal(want[1][0][0], want[2][0][0])
+    lanes = [(CapturedStep(head, f, l, r, both[0], own_scratch=True), torch.cuda.Stream()) for f, l, r, both in samples]
     main = torch.cuda.current_stream()
     for rnd in range(4):
         got = []
         for i, (cap, st) in enumerate(lanes):
             st.wait_stream(main)
+            which = (i + rnd) % 2
             with torch.cuda.stream(st):
-                p, d = cap.replay(img_metas=(metas, other)[(i + rnd) % 2])
-            got.append(((i + rnd) % 2, p, d))
+                p, d = cap.replay(img_metas=samples[i][3][which])
+            got.append((i, which, p, d))
         torch.cuda.synchronize()
-        for which, p, d in got:
-            assert torch.equal(p["all_bbox_preds"], want[which][0]) and torch.equal(d, want[which][1]), (rnd, which)
+        for i, which, p, d in got:
+            assert torch.equal(p["all_bbox_preds"], want[i][which][0]) and torch.equal(d, want[i][which][1]), (rnd, i, which)
+    for cap, _ in lanes:
+        cap.close()

@@ -9,7 +9,7 @@ import torch
 from conftest import GOLDEN
 from oracle import restate as R
 from racformer_amd import synthetic as syn
-from parity import decoder_parity, init_rig_params, load_rig_state_dict, oracle_decoder, run_with_reference_views
+from parity import ARGMAX_MARGIN_INIT_RIG, decoder_parity, init_rig_params, load_rig_state_dict, oracle_decoder, run_with_reference_views
 
 
 def load(golden_dir, name):
@@ -127,7 +127,7 @@ def test_decoder_f8_init_weights_rig_literal(golden_dir, name, cfg):
     g = load(golden_dir, name)
     torch.set_num_threads(min(16, os.cpu_count()))
     cls, box = _run_decoder(cfg, g)
-    rows = decoder_parity(cls, box, g["cls"], g["box"], what=name, tail_budget=None)
+    rows = decoder_parity(cls, box, g["cls"], g["box"], what=name, tail_budget=None, argmax_margin=ARGMAX_MARGIN_INIT_RIG)
     assert max(float(r["eb"].max()) for r in rows) < 2e-4        # measured 2.7e-5 / 4.2e-5: the rig does not amplify
 
 

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import restate as R
-from parity import (decode_parity, decoder_parity, detections_parity, fill_rig_module, flipped_points, head_boxes_normalised,
+from parity import (ARGMAX_MARGIN_INIT_RIG, decode_parity, decoder_parity, detections_parity, fill_rig_module, flipped_points, head_boxes_normalised,
                     kept_rows, oracle_decoder, run_with_reference_views, teacher_forced_layer_check)
 from racformer_amd import synthetic as syn
 from racformer_amd.head import RaCFormer_head
@@ -78,7 +78,8 @@ def test_decoder_f8_init_weights_rig_literal(golden_dir, name, cfg):
     seed, wseed = int(g["seed"]), int(g["weight_seed"])
     (cls, box, _), _ = run_with_reference_views(lambda force: run_decoder_gpu(cfg, seed, wseed, force, rig=(g, golden_dir)),
                                                 g["views"], name)
-    decoder_parity(cls, box, g["cls"], g["box"], what=name, tail_budget=None)
+    # (the tie rule at THIS rig's resolution: its CPU-vs-CPU logit drift is 4.2e-5, not the random rig's 1.2e-2)
+    decoder_parity(cls, box, g["cls"], g["box"], what=name, tail_budget=None, argmax_margin=ARGMAX_MARGIN_INIT_RIG)
 
 
 @pytest.mark.parametrize("name,cfg", [("decoder_small.npz", syn.SMALL), ("decoder_small6.npz", syn.SMALL6)])

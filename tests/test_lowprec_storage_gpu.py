@@ -1,0 +1,83 @@
+"""16-bit STORAGE of the sampled tensors, measured where it might legitimately pass (round-3 verdict, item 4) and asserted as
+measured -- profiles/r04_lowprec_storage.json holds the full table (tools/exp_lowprec.py).
+
+BASELINE configs 3 / 5 name bf16.  Round 3 measured bf16 storage only on the random-everything rig (which amplifies rounding
+4-5x per layer).  Here, with the reference's camera choices imposed and fp32 arithmetic throughout:
+
+(i)  bf16 PYRAMID on the rig as the reference initialises it (decoder_f8_init.npz / decoder_f8_3cam_init.npz -- the rig on
+     which fp32 is literal with 5e-5 / 1.1e-4 to spare): NOT literal.  6-cam: 2 / 4 of 900 queries over 1e-3 in layers 4 / 5
+     (max 3.3e-3) and two argmax changes in layer 1; 3-cam: queries over 1e-3 from layer 1 on, max 3.1e-2.  The fine levels
+     alone (c2: 75 % of the bytes) still lose one query in layers 4 and 5.  So bf16 pyramid storage stays an op-level option
+     (`decoder.feature_dtype`), is not benchmarked, and no mixed-dtype kernel is built.
+(ii) the two hoisted BEV VALUE STREAMS (what `bev_sampling_d64_kernel` gathers: 2 x 134 MB) with an fp32 pyramid:
+     bf16 is not literal on the init rig either (1 / 1 / 3 queries in layers 3-5); **f16 (11 significant bits) IS**: literal on
+     both init rigs (max 1.4e-4 / 7.0e-4, argmax identical) and on the random rig's decoder_f8.npz (max 7.5e-4, nothing over
+     1e-3) -- but on that rig's chaotic seed (decoder_f8_s1.npz, where fp32 itself has 1 / 8 queries over 1e-3 in layers
+     4 / 5) it has 8 / 33, beyond the tail budget the fp32 path is held to (4 / 12).  f16 value streams would halve the
+     bytes through the CU's texture path that bound the BEV kernel, so the result is recorded precisely; the
+     default keeps fp32 because one committed fixture fails with it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lowprec import GOLD, rig_inputs, run
+from parity import TAIL_QUERIES
+from racformer_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+@pytest.mark.parametrize("name,cfg", [("decoder_f8_init.npz", syn.F8), ("decoder_f8_3cam_init.npz", syn.F8_3CAM)])
+def test_init_rig_bf16_pyramid_and_16bit_value_streams_measured(name, cfg):
+    g = _g(name)
+    inputs = rig_inputs(cfg, int(g["seed"]))
+    fp32 = run(cfg, g, inputs, True)
+    assert sum(fp32["queries_over_1e-3"]) == 0 and sum(fp32["argmax_mismatches"]) == 0 and max(fp32["box_max"]) < 2e-4
+    # (i) bf16 pyramid: one layer inside the tolerance, six free-running layers not literal
+    pyr = run(cfg, g, inputs, True, pyramid_dtype=torch.bfloat16)
+    print(name, "pyramid bf16:", pyr)
+    assert pyr["box_max"][0] < 1e-3 and pyr["argmax_mismatches"][0] == 0
+    assert sum(pyr["queries_over_1e-3"]) + sum(pyr["argmax_mismatches"]) > 0, \
+        "bf16 pyramid storage is now literal on the init rig: ship it as an opt-in with a second bench line and update DESIGN 3.11"
+    assert max(pyr["queries_over_1e-3"]) <= 12 and max(pyr["box_max"]) < 0.1              # ... but bounded: a handful of queries
+    c2 = run(cfg, g, inputs, True, round_levels=(0,))
+    print(name, "pyramid c2 bf16:", c2)
+    assert sum(c2["queries_over_1e-3"][:4]) == 0 and sum(c2["queries_over_1e-3"]) <= 6        # (measured 2 / 1: at the edge of the tolerance)
+    # (ii) BEV value streams: bf16 not literal, f16 literal
+    vb = run(cfg, g, inputs, True, value_dtype=torch.bfloat16)
+    print(name, "values bf16:", vb)
+    assert sum(vb["queries_over_1e-3"]) > 0 and max(vb["queries_over_1e-3"]) <= 12
+    vh = run(cfg, g, inputs, True, value_dtype=torch.float16)
+    print(name, "values f16:", vh)
+    assert max(vh["value_abs_max"].values()) < 6.0e4                                         # (inside f16's range on this rig: no scale needed)
+    assert sum(vh["queries_over_1e-3"]) == 0 and sum(vh["argmax_mismatches"]) == 0 and max(vh["box_max"]) < 1e-3
+
+
+def test_random_rig_f16_value_streams_measured():
+    """f16 value streams on the rig that amplifies rounding: inside the tolerance on decoder_f8.npz, outside the fp32 path's
+    tail budget on the chaotic seed."""
+    cfg = syn.F8
+    g = _g("decoder_f8.npz")
+    inputs = rig_inputs(cfg, int(g["seed"]))
+    vh = run(cfg, g, inputs, False, value_dtype=torch.float16)
+    print("decoder_f8.npz values f16:", vh)
+    assert sum(vh["queries_over_1e-3"]) == 0 and sum(vh["argmax_mismatches"]) == 0
+    vb = run(cfg, g, inputs, False, value_dtype=torch.bfloat16)
+    print("decoder_f8.npz values bf16:", vb)
+    assert vb["queries_over_1e-3"][5] > TAIL_QUERIES[5]
+    del inputs
+    torch.cuda.empty_cache()
+    g = _g("decoder_f8_s1.npz")
+    inputs = rig_inputs(cfg, int(g["seed"]))
+    fp32 = run(cfg, g, inputs, False)
+    vh = run(cfg, g, inputs, False, value_dtype=torch.float16)
+    print("decoder_f8_s1.npz fp32:", fp32, "\nvalues f16:", vh)
+    assert all(a <= b for a, b in zip(fp32["queries_over_1e-3"], TAIL_QUERIES))
+    assert vh["queries_over_1e-3"][5] > TAIL_QUERIES[5] and max(vh["box_max"]) < 5e-2, \
+        "f16 value streams now stay inside the tail budget on the chaotic seed: make them the BEV kernel's storage (DESIGN 3.2)"

@@ -181,7 +181,59 @@ def stress_block(cfg, device, reps=20):
     b_alg = min(taps, value.numel() * 4) + mloc.numel() * 4 + attn.numel() * 4 + bs * Q * heads * 64 * 4
     out["rac_msda_fwd"] = {"avg_launch_ms": ms, "algorithmic_bytes": b_alg, "achieved": b_alg / (ms * 1e-3) / 1e9,
                            "unit": "GB/s", "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    del value
+    # Rows f2 / f4 at the reference's sizes (round-3 verdict, item 7): the backward operators at the launch shapes above, and
+    # bev_pool_v2 on the f8 Lift-Splat shape.  Timed is the operator as the autograd Function runs it (gradient buffers zeroed /
+    # allocated inside).  The feature / value gradients are scattered with memory-side float atomics, whose chip-wide rate is
+    # ~1.3 TB/s of added bytes (MI355X_MICROARCH.md): `atomic_frac` prices the scattered bytes against THAT, `frac` all bytes against HBM.
+    from racformer_amd.msda import MultiScaleDeformableAttnFunction_fp32 as _F32
+    from racformer_amd.msmv import msmv_backward
+    ATOMIC_PEAK_GBS = 1300.0
+    g_out = torch.randn(bs, Q, heads * 64, generator=g).to(device)
+    v_, l_, a_ = value.requires_grad_(), mloc.requires_grad_(), attn.requires_grad_()
+    o_ = _F32.apply(v_, torch.tensor([[H, W]], device=device), torch.tensor([0], device=device), l_, a_, 64)
+    ms = timed(lambda: torch.autograd.grad(o_, (v_, l_, a_), g_out, retain_graph=True))
+    scat = taps                                                     # every tap adds one 256-byte row of the value gradient
+    b_alg = scat + min(taps, value.numel() * 4) + g_out.numel() * 4 + 2 * (mloc.numel() + attn.numel()) * 4 + value.numel() * 4
+    out["rac_msda_bwd"] = {"avg_launch_ms": ms, "algorithmic_bytes": b_alg, "scattered_atomic_bytes": scat, "achieved": b_alg / (ms * 1e-3) / 1e9,
+                           "unit": "GB/s", "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "atomic_frac": scat / (ms * 1e-3) / 1e9 / ATOMIC_PEAK_GBS,
+                           "note": "incl. zeroing the 134 MB value gradient; grad_loc / grad_attn one writer per element"}
+    del value, v_, o_
+    feats = [torch.randn(S, N, h, w, C, generator=g).to(device) for (h, w) in cfg.fpn_hw]
+    g_out = torch.randn(S, Q, C, P, generator=g).to(device)
+    ms = timed(lambda: msmv_backward(g_out, feats, loc, w))
+    fb, fr = msmv_algorithmic_bytes(loc.cpu(), [tuple(f.shape) for f in feats], 4, S * Q * C * P)
+    scat = int(sum(fr) * S * Q * P) * 4 * C * 4                      # in-range (point, level) pairs x 4 taps x 256 B
+    b_alg = fb + scat + sum(f.numel() for f in feats) * 4 + (loc.numel() + w.numel()) * 4
+    out["rac_msmv_bwd"] = {"avg_launch_ms": ms, "algorithmic_bytes": b_alg, "scattered_atomic_bytes": scat, "achieved": b_alg / (ms * 1e-3) / 1e9,
+                           "unit": "GB/s", "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "atomic_frac": scat / (ms * 1e-3) / 1e9 / ATOMIC_PEAK_GBS,
+                           "note": "incl. zeroing the 735 MB feature gradient; grad_loc / grad_weight one writer per element"}
+    del feats, g_out
+    from racformer_amd.bev_pool import QuickCumsumCuda, intervals_from_ranks
+    Nc, Dd, Hh, Ww, Cc, Gg = 6, 96, 16, 44, 256, 128                 # configs/racformer_r50_nuimg_704x256_f8.py:55-63,100-104
+    rd, rf, rb = (t_.to(device) for t_ in syn.make_lss_ranks(Nc, Dd, Hh, Ww, Gg))
+    depth = torch.softmax(torch.randn(1, Nc, Dd, Hh, Ww, generator=g), 2).to(device).requires_grad_()
+    feat = torch.randn(1, Nc, Hh, Ww, Cc, generator=g).to(device).requires_grad_()
+    gs, gl = intervals_from_ranks(rb)
+    shape = (1, 1, Gg, Gg, Cc)
+    with torch.no_grad():
+        ms = timed(lambda: QuickCumsumCuda.apply(depth, feat, rd, rf, rb, shape, gs, gl))
+    n_pts = rd.numel()
+    b_alg = n_pts * (Cc * 4 + 4 + 12) + gs.numel() * 8 + 2 * Gg * Gg * Cc * 4            # feature row + depth + 3 ranks per point; cells zeroed + written
+    out["rac_bev_pool_v2_fwd"] = {"avg_launch_ms": ms, "points": n_pts, "cells": int(gs.numel()), "algorithmic_bytes": b_alg,
+                                  "achieved": b_alg / (ms * 1e-3) / 1e9, "unit": "GB/s", "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "f8 Lift-Splat shape: 6 cams x 96 depth bins x 16x44 -> 128x128 cells x 256 channels; feature rows are "
+                                          "re-read out of L2 (1.3 MB feature map)"}
+    o_ = QuickCumsumCuda.apply(depth, feat, rd, rf, rb, shape, gs, gl)
+    g_o = torch.randn(tuple(o_.shape), generator=g).to(device)
+    ms = timed(lambda: torch.autograd.grad(o_, (depth, feat), g_o, retain_graph=True))
+    b_alg = n_pts * (2 * Cc * 4 + 4 + 12 + 4) + feat.numel() * 4 + depth.numel() * 4
+    out["rac_bev_pool_v2_bwd"] = {"avg_launch_ms": ms, "algorithmic_bytes": b_alg, "achieved": b_alg / (ms * 1e-3) / 1e9, "unit": "GB/s",
+                                  "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "incl. the stable sort by feature cell and the interval tables (torch ops, as bev_pool.py:50-63 prepares "
+                                          "them); no atomics: one writer per gradient element"}
+    del depth, feat, o_, g_o
     # The FUSED kernel (keypoints + projection + view selection + gather) on a scattered-query set: boxes anywhere in the
     # range (theta, d uniform; z, sizes, yaw, velocity random), the three sampling Linears' outputs ~ N(0,1) (offsets, ray
     # jitter, level logits -- what a random-feature query would produce), N(0,1) maps, the rig's own cameras and timestamps.

@@ -54,11 +54,11 @@
 extern "C" {
 #endif
 
-#define RAC_ABI_VERSION 4
+#define RAC_ABI_VERSION 5
 #define RAC_MAX_LEVELS 8
 #define RAC_MAX_POINTS 128 /* same limit as the reference, msmv_sampling_forward.cu:21 */
 
-enum { RAC_F32 = 0, RAC_BF16 = 1 };
+enum { RAC_F32 = 0, RAC_BF16 = 1, RAC_I16 = 2 /* int16 block storage of a BEV value stream: rac_quant_i16_fwd */ };
 
 enum {
     RAC_E_ARG = -1,      /* bad size / null pointer */
@@ -165,6 +165,24 @@ int rac_bev_sampling_multi_fwd(int nstreams, const void *const *values, const fl
                                const float *box_table, const float *time_diff, int ld_off, int ld_ray, int ld_scale,
                                int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W, int dim,
                                const float *pc_range, const float *depth_base, float d_region, int dtype, void *stream);
+
+/* Opt-in 16-bit BLOCK storage of a hoisted BEV value stream (round 4; the default keeps fp32): values [blocks][64] f32 -- one
+ * block = the 64 channels of one head at one pixel of one frame, i.e. the unit one tap of the BEV kernel reads -- become int16
+ * mantissas q [blocks][64] and one power-of-two scale per block, value = q * scale[block] (14-15 significant bits relative to
+ * the block's largest value).  Not a reference interface: the reference keeps fp32 value maps (bev_self_attention.py:162-174);
+ * this is the storage format of rac_bev_sampling_multi_q16_fwd below. */
+int rac_quant_i16_fwd(const float *values, void *q, float *scale, int64_t blocks, void *stream);
+
+/* rac_bev_sampling_multi_fwd over int16 block-stored value streams: values[i] int16 [B*T, H*W, heads, 64], value_scales[i] f32
+ * [B*T, H*W, heads] from rac_quant_i16_fwd; everything else as above (same arithmetic in fp32; each tap's scale is folded into
+ * its bilinear weight).  Halves the bytes the kernel gathers. */
+int rac_bev_sampling_multi_q16_fwd(int nstreams, const void *const *values, const float *const *value_scales,
+                                   const float *const *offsets, const float *const *ray_logits,
+                                   const float *const *scale_logits, const float *const *queue_logits, float *const *outs,
+                                   const float *query_bbox, const float *box_table, const float *time_diff, int ld_off,
+                                   int ld_ray, int ld_scale, int ld_queue, int B, int T, int Q, int heads, int NP, int D,
+                                   int H, int W, int dim, const float *pc_range, const float *depth_base, float d_region,
+                                   void *stream);
 
 /* Scale-adaptive self-attention core (QK^T + distance mask + softmax + AV), one kernel.
  * Replaces calc_bbox_dists, the [B*heads,Q,Q] mask and nn.MultiheadAttention's attention product

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (RACFORMER_HIP_LIB: another build of the same library, for A/B experiments of tools/exp_*.py; never set in tests or bench)
 LIB_PATH = os.environ.get("RACFORMER_HIP_LIB") or os.path.join(_HERE, "csrc", "libracformer_hip.so")
-RAC_F32, RAC_BF16 = 0, 1
+RAC_F32, RAC_BF16, RAC_I16 = 0, 1, 2
 OUT_SQCP, OUT_BQGTPC = 0, 1
 MIX_F32, MIX_F16X3 = 0, 1
 _lib = None
@@ -54,6 +54,8 @@ SIGNATURES = {
     "rac_conv3x3s2_fwd": (_i, [_vp] * 4 + [_f, _vp] + [_i] * 7 + [_vp]),
     "rac_bev_sampling_fwd": (_i, [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
     "rac_bev_sampling_multi_fwd": (_i, [_i] + [_vp] * 9 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
+    "rac_bev_sampling_multi_q16_fwd": (_i, [_i] + [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _vp]),
+    "rac_quant_i16_fwd": (_i, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
 }
 
 

@@ -34,6 +34,7 @@ struct BevStream {
     const float *queue;      // [B,Q,T] logits
     float *out;              // [B,Q,heads*64]
     float *loc_out;          // optional [B,Q,heads,T,P,2]
+    const float *vscale;     // int16 block storage only: [B*T, H*W, heads] scale of each (pixel, head) block (quant.hip)
 };
 struct BevArgs {
     BevStream s[BEV_MAX_STREAMS];
@@ -131,6 +132,13 @@ __device__ __forceinline__ rac_f4 bev_tap<unsigned short>(__amdgpu_buffer_rsrc_t
     const bev_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);    // 4 x bf16
     return (rac_f4){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
                     __uint_as_float(r.y & 0xffff0000u)};
+}
+
+template <>
+__device__ __forceinline__ rac_f4 bev_tap<short>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+{
+    const bev_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);    // 4 x int16 mantissas (the block's scale rides in the tap weight)
+    return (rac_f4){(float)(short)(r.x & 0xffffu), (float)((int)r.x >> 16), (float)(short)(r.y & 0xffffu), (float)((int)r.y >> 16)};
 }
 
 // per-(t,p) half of the keypoint chain for B==1: warp the T-invariant base point, polar jitter.
@@ -314,7 +322,18 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
             off.z = b_ok && l_ok ? fbase + (unsigned)(h_high * W + w_low) * pix_bytes : BEV_TAP_OUTSIDE;
             off.w = b_ok && r_ok ? fbase + (unsigned)(h_high * W + w_high) * pix_bytes : BEV_TAP_OUTSIDE;
             *reinterpret_cast<bev_u4 *>(e) = off;
-            *reinterpret_cast<rac_f4 *>(e + 4) = (rac_f4){hh * hw * wgt, hh * lw * wgt, lh * hw * wgt, lh * lw * wgt};
+            rac_f4 tw = {hh * hw * wgt, hh * lw * wgt, lh * hw * wgt, lh * lw * wgt};
+            if (sizeof(FT) == 2 && s.vscale) {
+                // int16 block storage: the scale of each tap's (pixel, head) block, folded into its weight (a tap outside the map
+                // reads zeros whatever its weight)
+                const float *sb = s.vscale + ((size_t)(b * T + t) * (size_t)(H * W)) * a.heads + h;
+                const float s0 = t_ok && l_ok ? sb[(size_t)(h_low * W + w_low) * a.heads] : 0.f;
+                const float s1 = t_ok && r_ok ? sb[(size_t)(h_low * W + w_high) * a.heads] : 0.f;
+                const float s2 = b_ok && l_ok ? sb[(size_t)(h_high * W + w_low) * a.heads] : 0.f;
+                const float s3 = b_ok && r_ok ? sb[(size_t)(h_high * W + w_high) * a.heads] : 0.f;
+                tw.x *= s0; tw.y *= s1; tw.z *= s2; tw.w *= s3;
+            }
+            *reinterpret_cast<rac_f4 *>(e + 4) = tw;
         }
         if (s.loc_out) {
             float *lo = s.loc_out + (((((size_t)b * a.Q + q) * a.heads + h) * T + t) * P + p) * 2;
@@ -392,7 +411,7 @@ extern "C" int rac_dbg_bev_stamps(unsigned long long *host_out, int n_wgs)
 }
 #endif
 
-static int bev_launch(int nstreams, const void *const *values, const float *const *offsets, const float *const *ray_logits,
+static int bev_launch(int nstreams, const void *const *values, const float *const *vscales, const float *const *offsets, const float *const *ray_logits,
                       const float *const *scale_logits, const float *const *queue_logits, float *const *outs, float *const *loc_outs,
                       const float *query_bbox, const float *box_table, const float *time_diff, int ld_off, int ld_ray,
                       int ld_scale, int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W, int dim,
@@ -402,14 +421,15 @@ static int bev_launch(int nstreams, const void *const *values, const float *cons
     RAC_CHECK_ARG(dim == 64, "rac_bev_sampling_fwd: dim=%d (the fused kernel is built for 64 channels per head)", dim);
     RAC_CHECK_ARG(B >= 0 && Q >= 0 && T >= 1 && heads >= 1 && NP >= 1 && D >= 1 && D <= BEV_MAX_DEPTH && H >= 1 && W >= 1,
                   "rac_bev_sampling_fwd: bad sizes B=%d T=%d Q=%d heads=%d NP=%d D=%d H=%d W=%d", B, T, Q, heads, NP, D, H, W);
-    RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16, "rac_bev_sampling_fwd: dtype %d", dtype);
+    RAC_CHECK_ARG(dtype == RAC_F32 || dtype == RAC_BF16 || dtype == RAC_I16, "rac_bev_sampling_fwd: dtype %d", dtype);
+    RAC_CHECK_ARG((dtype == RAC_I16) == (vscales != nullptr), "rac_bev_sampling_fwd: int16 value streams come with their scale tables (and only they)");
     const int P = NP * D;
     const int npp = (P + BEV_TS - 1) / BEV_TS;
     const int list_len = (T * npp + BEV_U - 1) / BEV_U * BEV_U;
     const size_t lds = ((size_t)BEV_GI * BEV_TS * list_len * 8 + (size_t)BEV_GI * BEV_TS * 64 + (size_t)BEV_GI * (B > 1 ? T : 1) * P +
                         (size_t)BEV_GI * T + (size_t)BEV_GI * P * 2 + (size_t)BEV_GI * BEV_MAX_DEPTH + (size_t)BEV_GI * 2 + (size_t)T) * sizeof(float);
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_bev_sampling_fwd: T*P=%d too large for the LDS staging", T * P);
-    const size_t value_bytes = (size_t)B * T * H * W * heads * 64 * (dtype == RAC_F32 ? 4 : 2);
+    const size_t value_bytes = (size_t)B * T * H * W * heads * 64 * (dtype == RAC_F32 ? 4 : 2);   // (bf16 and int16: 2 bytes)
     RAC_CHECK_ARG(value_bytes < (size_t)BEV_TAP_OUTSIDE, "rac_bev_sampling_fwd: value maps of %zu bytes (the tap offsets are 31-bit)", value_bytes);
     if (B == 0 || Q == 0)
         return 0;
@@ -426,6 +446,8 @@ static int bev_launch(int nstreams, const void *const *values, const float *cons
                       "rac_bev_sampling_fwd: null pointer in stream %d", j);
         a.s[i].value = values[j]; a.s[i].off = offsets[j]; a.s[i].ray = ray_logits[j]; a.s[i].scale = scale_logits[j];
         a.s[i].queue = queue_logits[j]; a.s[i].out = outs[j]; a.s[i].loc_out = loc_outs ? loc_outs[j] : nullptr;
+        a.s[i].vscale = vscales ? vscales[j] : nullptr;
+        RAC_CHECK_ARG(!vscales || vscales[j], "rac_bev_sampling_fwd: null scale table in stream %d", j);
     }
     a.qbox = query_bbox; a.box = box_table; a.time_diff = time_diff;
     for (int i = 0; i < BEV_MAX_DEPTH; ++i)
@@ -444,6 +466,8 @@ static int bev_launch(int nstreams, const void *const *values, const float *cons
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RAC_F32)
         hipLaunchKernelGGL(bev_sampling_d64_kernel<float>, grid, dim3(256), lds, st, a);
+    else if (dtype == RAC_I16)
+        hipLaunchKernelGGL(bev_sampling_d64_kernel<short>, grid, dim3(256), lds, st, a);
     else
         hipLaunchKernelGGL(bev_sampling_d64_kernel<unsigned short>, grid, dim3(256), lds, st, a);
     return rac_launch_status("rac_bev_sampling_fwd");
@@ -457,7 +481,7 @@ extern "C" int rac_bev_sampling_fwd(const void *value, const float *query_bbox, 
                                     int NP, int D, int H, int W, int dim, const float *pc_range,
                                     const float *depth_base, float d_region, int dtype, void *stream)
 {
-    return bev_launch(1, &value, &offsets, &ray_logits, &scale_logits, &queue_logits, &out, &loc_out, query_bbox, box_table, time_diff,
+    return bev_launch(1, &value, nullptr, &offsets, &ray_logits, &scale_logits, &queue_logits, &out, &loc_out, query_bbox, box_table, time_diff,
                       ld_off, ld_ray, ld_scale, ld_queue, B, T, Q, heads, NP, D, H, W, dim, pc_range, depth_base, d_region, dtype, stream);
 }
 
@@ -468,6 +492,20 @@ extern "C" int rac_bev_sampling_multi_fwd(int nstreams, const void *const *value
                                           int ld_queue, int B, int T, int Q, int heads, int NP, int D, int H, int W, int dim,
                                           const float *pc_range, const float *depth_base, float d_region, int dtype, void *stream)
 {
-    return bev_launch(nstreams, values, offsets, ray_logits, scale_logits, queue_logits, outs, nullptr, query_bbox, box_table, time_diff,
+    return bev_launch(nstreams, values, nullptr, offsets, ray_logits, scale_logits, queue_logits, outs, nullptr, query_bbox, box_table, time_diff,
                       ld_off, ld_ray, ld_scale, ld_queue, B, T, Q, heads, NP, D, H, W, dim, pc_range, depth_base, d_region, dtype, stream);
+}
+
+extern "C" int rac_bev_sampling_multi_q16_fwd(int nstreams, const void *const *values, const float *const *value_scales,
+                                              const float *const *offsets, const float *const *ray_logits,
+                                              const float *const *scale_logits, const float *const *queue_logits, float *const *outs,
+                                              const float *query_bbox, const float *box_table, const float *time_diff, int ld_off,
+                                              int ld_ray, int ld_scale, int ld_queue, int B, int T, int Q, int heads, int NP, int D,
+                                              int H, int W, int dim, const float *pc_range, const float *depth_base, float d_region,
+                                              void *stream)
+{
+    RAC_CHECK_ARG(value_scales != nullptr, "rac_bev_sampling_multi_q16_fwd: null scale tables");
+    return bev_launch(nstreams, values, value_scales, offsets, ray_logits, scale_logits, queue_logits, outs, nullptr, query_bbox, box_table,
+                      time_diff, ld_off, ld_ray, ld_scale, ld_queue, B, T, Q, heads, NP, D, H, W, dim, pc_range, depth_base, d_region,
+                      RAC_I16, stream);
 }

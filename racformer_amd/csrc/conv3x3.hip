@@ -28,6 +28,9 @@ typedef float cv_f4 __attribute__((ext_vector_type(4)));
 #ifndef CV_TAP_MAJOR
 #define CV_TAP_MAJOR 0
 #endif
+#ifndef CV_SPREAD_STAGING
+#define CV_SPREAD_STAGING 1   /* 0: all staging traffic at the top of the step (rounds 2-3; A/B builds) */
+#endif
 #define CV_TM 256
 #define CV_COUT 256
 #define CV_STAGE_U4 4096 /* uint4 per LDS stage: A 2048 + B 2048 */
@@ -234,12 +237,73 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
     CV_LSTORE(0);
     CV_GLOAD(KS > 1 ? 1 : 0);
     __syncthreads();
+#if CV_SPREAD_STAGING
+    // Round 4: the step's staging traffic -- eight LDS writes of tile ks+1 and the eight global loads of tile ks+2 that re-use
+    // their registers -- is dealt out over the eight MFMA groups of the step, one (write, load) pair per group, and the A
+    // fragments of group m+1 are read under the MFMAs of group m.  Before, all 64 ds_write_b128 of the workgroup hit the LDS
+    // at the top of the step (830 cycles of write path, the first fragment reads queued behind them): the matrix pipe sat
+    // idle for about a quarter of every step (PMC: 54 % MFMA-busy, 43 % of the wave cycles parked).
+    for (int ks = 0; ks < KS; ++ks) {
+        const int kn = ks + 2 < KS ? ks + 2 : KS - 1;   // (past the end the last tile is re-fetched / re-written: unconditional code)
+        const int chunk_ = CV_TAP_MAJOR ? kn % chunks : kn / 9;
+        const int tap_ = CV_TAP_MAJOR ? kn / chunks : kn - chunk_ * 9;
+        const int dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;
+        const size_t off_ = ((size_t)dy_ * Wp + dx_) * pix_stride + (size_t)chunk_ * 8;
+        const uint4 *wsrc_ = a.ws + (size_t)(tap_ * chunks + chunk_) * 2048 + tid;
+        uint4 *DA = lds4 + ((ks + 1) & 1) * CV_STAGE_U4, *DB = DA + 2048;
+        const cv_h8 *S = reinterpret_cast<const cv_h8 *>(lds4 + (ks & 1) * CV_STAGE_U4);
+        cv_h8 bh[4], bl[4], ah[2], al[2];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            bh[nn] = S[bidx_h[nn]];
+            bl[nn] = S[bidx_l[nn]];
+        }
+        {
+            const int row = arow0, f = (row >> 1) & 7;
+            ah[0] = S[row * 8 + (lk ^ f)];
+            al[0] = S[row * 8 + ((4 + lk) ^ f)];
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (m + 1 < 8) {
+                const int row = arow0 + 16 * (m + 1), f = (row >> 1) & 7;
+                ah[(m + 1) & 1] = S[row * 8 + (lk ^ f)];
+                al[(m + 1) & 1] = S[row * 8 + ((4 + lk) ^ f)];
+            }
+            switch (m) {     // staging piece m: tile ks+1 out of its register into the other LDS stage, tile ks+2 into the register
+            case 0: DA[st0] = ra0; ra0 = a.xs[a_base0 + off_]; break;
+            case 1: DA[st1] = ra1; ra1 = a.xs[a_base1 + off_]; break;
+            case 2: DA[st2] = ra2; ra2 = a.xs[a_base2 + off_]; break;
+            case 3: DA[st3] = ra3; ra3 = a.xs[a_base3 + off_]; break;
+            case 4: DB[st0] = rb0; rb0 = wsrc_[0]; break;
+            case 5: DB[st1] = rb1; rb1 = wsrc_[512]; break;
+            case 6: DB[st2] = rb2; rb2 = wsrc_[1024]; break;
+            default: DB[st3] = rb3; rb3 = wsrc_[1536]; break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nn], al[m & 1], acc[m][nn], 0, 0, 0);
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[nn], ah[m & 1], acc[m][nn], 0, 0, 0);
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nn], ah[m & 1], acc[m][nn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#else
     for (int ks = 0; ks < KS; ++ks) {
         // (past the end the last tile is re-fetched / re-written into the unused stage: unconditional code keeps the
         //  staging registers out of scratch)
         CV_LSTORE((ks + 1) & 1);
         const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
         CV_GLOAD(kn);
+        // (nothing may move across this line: without it hipcc re-uses the eight staging registers for A fragments during the MFMA
+        //  phase and sinks the loads of tile ks+2 to the END of the step)
+        __builtin_amdgcn_sched_barrier(0);
         const cv_h8 *S = reinterpret_cast<const cv_h8 *>(lds4 + (ks & 1) * CV_STAGE_U4);
         cv_h8 bh[4], bl[4];
 #pragma unroll
@@ -254,18 +318,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
             const cv_h8 al = S[row * 8 + ((4 + lk) ^ f)];
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nn], acc[m][nn], 0, 0, 0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nn], al, acc[m][nn], 0, 0, 0);
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nn], acc[m][nn], 0, 0, 0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[nn], ah, acc[m][nn], 0, 0, 0);
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nn], acc[m][nn], 0, 0, 0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nn], ah, acc[m][nn], 0, 0, 0);
         }
         __syncthreads();
     }
+#endif
 
-    // epilogue: undo the two power-of-two scalings, add the bias (per channel, or per pixel and channel), channel-last store
+    // epilogue: undo the two power-of-two scalings, add the bias (per channel, or per pixel and channel), channel-last store.
+    // The weights are the MFMA's A operand, so a 16x16 accumulator tile has its PIXEL on the lane (column li) and four
+    // consecutive output CHANNELS (rows 4 lk + r) in the lane's registers: one 16-byte store (and one 16-byte bias load) per
+    // tile instead of four 4-byte ones (round 4; the predicated 4-byte form also serialised 128 bias loads per lane).
     const float unscale = a.w_alpha / cv_act_scale(*a.amax);
     const int prows = min(CV_TM, HW - tile * CV_TM);       // valid pixels of this tile
     if (GROUPED) {
@@ -274,16 +342,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
         float *obase = a.out + ((((size_t)bt * 4 + wn) * a.cams + cam) * HW + (size_t)tile * CV_TM) * 64;
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) {
-            const int c = 16 * nn + li;
-            const float bv = a.bias ? a.bias[64 * wn + c] : 0.f;
+            const int c = 16 * nn + 4 * lk;
+            const cv_f4 bv = a.bias ? *reinterpret_cast<const cv_f4 *>(a.bias + 64 * wn + c) : (cv_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int p = 128 * wm + 16 * m + 4 * lk + r;
-                    if (p < prows)
-                        obase[(size_t)p * 64 + c] = acc[m][nn][r] * unscale + bv;
-                }
+            for (int m = 0; m < 8; ++m) {
+                const int p = 128 * wm + 16 * m + li;
+                if (p < prows)
+                    *reinterpret_cast<cv_f4 *>(obase + (size_t)p * 64 + c) = acc[m][nn] * unscale + bv;
+            }
         }
         return;
     }
@@ -291,18 +357,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
     const float *pbase = a.pixel_bias ? a.pixel_bias + (size_t)tile * CV_TM * CV_COUT : nullptr;
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
-        const int col = 64 * wn + 16 * nn + li;
-        const float bv = (!pbase && a.bias) ? a.bias[col] : 0.f;
+        const int col = 64 * wn + 16 * nn + 4 * lk;
+        const cv_f4 bv = (!pbase && a.bias) ? *reinterpret_cast<const cv_f4 *>(a.bias + col) : (cv_f4){0.f, 0.f, 0.f, 0.f};
+        cv_f4 pb[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
+        for (int m = 0; m < 8; ++m) {
+            const int p = min(128 * wm + 16 * m + li, prows - 1);      // (rows past a ragged tile re-read its last row; not stored)
+            pb[m] = pbase ? *reinterpret_cast<const cv_f4 *>(pbase + (size_t)p * CV_COUT + col) : bv;
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = 128 * wm + 16 * m + 4 * lk + r;
-                if (p < prows) {
-                    const float pb = pbase ? pbase[(size_t)p * CV_COUT + col] : bv;
-                    obase[(size_t)p * CV_COUT + col] = acc[m][nn][r] * unscale + pb;
-                }
-            }
+        for (int m = 0; m < 8; ++m) {
+            const int p = 128 * wm + 16 * m + li;
+            if (p < prows)
+                *reinterpret_cast<cv_f4 *>(obase + (size_t)p * CV_COUT + col) = acc[m][nn] * unscale + pb[m];
+        }
     }
 }
 
@@ -397,6 +465,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv3x3s2_c64_f16x3_kernel(cons
         S2_LSTORE((ks + 1) & 1);
         const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
         S2_GLOAD(kn);
+        __builtin_amdgcn_sched_barrier(0);   // (as in conv3x3_f16x3_kernel: the loads stay at the top of the step)
         const cv_h8 *S = reinterpret_cast<const cv_h8 *>(lds4 + (ks & 1) * STAGE);
         cv_h8 bh[4], bl[4];
 #pragma unroll
@@ -499,6 +568,8 @@ extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias
     if (N == 0)
         return 0;
     RAC_CHECK_ARG(xs && ws && amax && out, "rac_conv3x3_fwd: null pointer");
+    RAC_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pixel_bias)) & 15) == 0,
+                  "rac_conv3x3_fwd: out / bias / pixel_bias must be 16-byte aligned");
     ConvArgs a;
     a.xs = reinterpret_cast<const uint4 *>(xs);
     a.ws = reinterpret_cast<const uint4 *>(ws);
@@ -521,6 +592,8 @@ extern "C" int rac_fpn_conv_fwd(const void *xs, const void *ws, const float *bia
     if (num_images == 0)
         return 0;
     RAC_CHECK_ARG(xs && ws && amax && out, "rac_fpn_conv_fwd: null pointer");
+    RAC_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                  "rac_fpn_conv_fwd: out / bias must be 16-byte aligned");
     ConvArgs a;
     a.xs = reinterpret_cast<const uint4 *>(xs);
     a.ws = reinterpret_cast<const uint4 *>(ws);

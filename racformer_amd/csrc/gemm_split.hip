@@ -241,6 +241,9 @@ __global__ __launch_bounds__(768, 1) void gemm_split_kernel(const GemmSplitArgs 
 #define GW_ROWS 32                          /* X rows per stage */
 #define GW_STAGE (GW_ROWS * 1024)           /* bytes: K = 256 -> 8 lines = 1 KB per row */
 #define GW_STAGES 4
+#ifndef GW_UNROLL
+#define GW_UNROLL 4                         /* stages per trip of the stage loop (a multiple of GW_STAGES) */
+#endif
 
 struct GenArgs {
     const char *x;      // X image [M][8 lines]
@@ -305,13 +308,19 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
         bias4[t] = (g.bias && n + 3 < g.N) ? *reinterpret_cast<const gs_f4 *>(g.bias + n) : (gs_f4){0.f, 0.f, 0.f, 0.f};
     }
     // (the waits below are spelled out: everything issued so far -- 12 pieces and 32 weight loads -- has to be complete)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (as a builtin, so that hipcc's own wait-count bookkeeping knows the weight registers have landed: behind an inline-asm wait it
+    //  still placed a vmcnt(0) in front of their first use inside the stage loop -- once per trip, draining the stores of the stage before)
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // fragment read: row r = 16j + li of the stage, chunk c = 8 ks + (hi: lk, lo: 4 + lk), LDS slot c ^ (r & 15) = c ^ li
-    for (int st0 = 0; st0 < nstages; st0 += GW_STAGES) {
+    // A trip of the outer loop is GW_UNROLL stages with compile-time ring slots.  At the trip's first fragment read hipcc drains
+    // vmcnt(0) (above) -- which also waits for the STORES of the stage before: one exposed store round trip per trip.  With four
+    // stages per trip that was 7 drains per workgroup at 900 rows; with 16 it is two (round 4: ISA + PMC).
+    for (int st0 = 0; st0 < nstages; st0 += GW_UNROLL) {
 #pragma unroll
-    for (int u = 0; u < GW_STAGES; ++u) {
+    for (int u = 0; u < GW_UNROLL; ++u) {
         const int st = st0 + u;
         if (st >= nstages)
             break;
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
         // nothing (the older ones have landed), with them issued it exposed one full memory latency every four stages
         if (u != 0 && st + 3 < nstages)
             issue(st + 3, (u + 3) & (GW_STAGES - 1));
-        const char *S = lds + u * GW_STAGE;
+        const char *S = lds + (u & (GW_STAGES - 1)) * GW_STAGE;
         gs_f4 acc[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)

@@ -81,6 +81,12 @@ __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs 
     for (int t = 0; t < 2; ++t)
         bias4[t] = (g.bias && !g.add) ? *reinterpret_cast<const vp_f4 *>(g.bias + 32 * wave + 16 * t + 4 * lk) : (vp_f4){0.f, 0.f, 0.f, 0.f};
 
+    // Everything issued so far (the 32 weight fragments, stage 0's pixels) has to have LANDED before the stage loop is entered,
+    // and the compiler has to know it: hipcc places the vmcnt waits for the weight registers at their first uses INSIDE the loop
+    // (vmcnt(30) ... vmcnt(0) between the MFMAs), and from the second stage on those same waits drain the loads of the NEXT
+    // stage that were issued just above them -- the prefetch ran inside the MFMA phase instead of under it (round-4 ISA reading:
+    // 63 % of the wave cycles parked in s_waitcnt).  simm16 = vmcnt(0), expcnt / lgkmcnt untouched.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int st = 0; st < nstages; ++st) {
         char *B = lds + (st & 1) * VP_BUF;
         float *salpha = reinterpret_cast<float *>(B + VP_ROWS * 1024);
@@ -131,8 +137,22 @@ __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs 
             *reinterpret_cast<vp_h4 *>(rowp + (((8 * wave + 4 + (cs >> 1)) ^ (r & 15)) * 16)) = lo;
         }
         __syncthreads();                                  // (B) the stage's X image is complete
-        if (st + 1 < nstages)
-            load(st + 1, xv);                             // in flight under the MFMAs
+        // this stage's additive term first, then the next stage's pixels: both in flight under the MFMAs, and the epilogue's
+        // wait for the (older) additive term leaves the pixel loads outstanding (loaded inside the epilogue, each of the four
+        // loads was followed by a vmcnt(0) that drained the prefetch as well)
+        const long gp = m0 + (long)st * VP_ROWS;
+        const int p0 = (int)(gp % g.HW);
+        vp_f4 addv[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const long row = min(gp + 16 * j + li, mend - 1) - gp;          // (rows past the end re-read the last row; not stored)
+                addv[j][t] = g.add ? *reinterpret_cast<const vp_f4 *>(g.add + (size_t)(p0 + row) * 256 + 32 * wave + 16 * t + 4 * lk) : bias4[t];
+            }
+        // (unconditional -- past the end the last stage is fetched again and never used: a branch around these loads would make
+        //  the number of loads in flight path-dependent, and the epilogue's wait for the additive term would fall back to vmcnt(0))
+        load(st + 1 < nstages ? st + 1 : st, xv);         // in flight under the MFMAs
         __builtin_amdgcn_sched_barrier(0);
 
         vp_f4 acc[2][2];
@@ -157,8 +177,6 @@ __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs 
             }
         }
         // ---- epilogue: C/D layout col = li (pixel), rows 4 lk + r = four consecutive features: one 16-byte store
-        const long gp = m0 + (long)st * VP_ROWS;
-        const int p0 = (int)(gp % g.HW);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = 16 * j + li;
@@ -167,10 +185,7 @@ __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs 
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int n = 32 * wave + 16 * t + 4 * lk;
-                    vp_f4 v = acc[t][j] * a + bias4[t];
-                    if (g.add)
-                        v += *reinterpret_cast<const vp_f4 *>(g.add + (size_t)(p0 + r) * 256 + n);
-                    *reinterpret_cast<vp_f4 *>(g.out + (size_t)(gp + r) * 256 + n) = v;
+                    *reinterpret_cast<vp_f4 *>(g.out + (size_t)(gp + r) * 256 + n) = acc[t][j] * a + addv[j][t];
                 }
             }
         }

@@ -133,10 +133,31 @@ def bev_sampling_fused(value, hw, query_bbox, offsets, ray_logits, scale_logits,
     return (out, loc_out) if debug else out
 
 
+def quantize_values_i16(value):
+    """A hoisted value stream [B*T, H*W, heads, 64] f32 -> (int16 mantissas of the same shape, scales [B*T, H*W, heads] f32):
+    one power-of-two scale per (pixel, head) block of 64 channels, value = q * scale (rac_quant_i16_fwd; opt-in storage of
+    RaCFormerTransformerDecoderLayer.value_storage = "i16")."""
+    _lib.require_gpu(value, what="quantize_values_i16")
+    if value.dtype != torch.float32 or value.shape[-1] != 64:
+        raise RuntimeError("quantize_values_i16: float32 [..., 64] value stream expected")
+    q = torch.empty(value.shape, device=value.device, dtype=torch.int16)
+    scale = torch.empty(value.shape[:-1], device=value.device, dtype=torch.float32)
+    ev = _lib.timer.record("quant_i16_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_quant_i16_fwd(_lib.ptr(value), _lib.ptr(q), _lib.ptr(scale), scale.numel(), _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_quant_i16_fwd")
+    return q, scale
+
+
 def bev_sampling_multi_fused(streams, hw, query_bbox, time_diff, num_frames, num_heads, num_points, depth_num, pc_range,
-                             d_region, box_table, out):
+                             d_region, box_table, out, value_scales=None):
     """The BEV streams of one decoder layer in one launch (rac_bev_sampling_multi_fwd).  ``streams``: list of
-    (value [B*T,H*W,heads,64], offsets, ray_logits, scale_logits, queue_logits) with equal row strides; ``out`` [n,B,Q,heads*64]."""
+    (value [B*T,H*W,heads,64], offsets, ray_logits, scale_logits, queue_logits) with equal row strides; ``out`` [n,B,Q,heads*64].
+    ``value_scales``: per stream the [B*T,H*W,heads] scale table of an int16 block-stored value stream (quantize_values_i16;
+    rac_bev_sampling_multi_q16_fwd)."""
     B, Q, _ = query_bbox.shape
     T, Hn, NP, D = num_frames, num_heads, num_points, depth_num
     P = NP * D
@@ -166,10 +187,23 @@ def bev_sampling_multi_fused(streams, hw, query_bbox, time_diff, num_frames, num
     ev = _lib.timer.record(f"bev_sampling_x{n}_fwd") if _lib.timer is not None else None
     if ev:
         ev[0].record()
-    rc = _lib.lib().rac_bev_sampling_multi_fwd(
-        n, arr[0], arr[1], arr[2], arr[3], arr[4], outs, _lib.ptr(query_bbox), _lib.ptr(box_table), _lib.ptr(time_diff),
-        lds[0], lds[1], lds[2], lds[3], B, T, Q, Hn, NP, D, H, W, 64, pc, _depth_base(float(d_region), D), float(d_region),
-        _lib.dtype_code(streams[0][0]), _lib.stream_ptr())
+    if value_scales is not None:
+        if len(value_scales) != n or any(v[0].dtype != torch.int16 for v in streams):
+            raise RuntimeError("bev_sampling_multi_fused: int16 value streams and one scale table per stream expected")
+        for sc_ in value_scales:
+            _lib.require_gpu(sc_, what="bev_sampling_multi_fused(value_scales)")
+            if tuple(sc_.shape) != (B * T, H * W, Hn) or sc_.dtype != torch.float32:
+                raise RuntimeError(f"bev_sampling_multi_fused: scale table must be f32 [{B * T},{H * W},{Hn}]")
+        vsc = (ctypes.c_void_p * n)(*[sc_.data_ptr() for sc_ in value_scales])
+        rc = _lib.lib().rac_bev_sampling_multi_q16_fwd(
+            n, arr[0], vsc, arr[1], arr[2], arr[3], arr[4], outs, _lib.ptr(query_bbox), _lib.ptr(box_table), _lib.ptr(time_diff),
+            lds[0], lds[1], lds[2], lds[3], B, T, Q, Hn, NP, D, H, W, 64, pc, _depth_base(float(d_region), D), float(d_region),
+            _lib.stream_ptr())
+    else:
+        rc = _lib.lib().rac_bev_sampling_multi_fwd(
+            n, arr[0], arr[1], arr[2], arr[3], arr[4], outs, _lib.ptr(query_bbox), _lib.ptr(box_table), _lib.ptr(time_diff),
+            lds[0], lds[1], lds[2], lds[3], B, T, Q, Hn, NP, D, H, W, 64, pc, _depth_base(float(d_region), D), float(d_region),
+            _lib.dtype_code(streams[0][0]), _lib.stream_ptr())
     if ev:
         ev[1].record()
     _lib.check(rc, "rac_bev_sampling_multi_fwd")

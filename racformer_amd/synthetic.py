@@ -171,6 +171,28 @@ def make_bev(cfg: RigConfig, seed=0, which=0):
     return torch.from_numpy(a)
 
 
+# ------------------------------------------------------------------ Lift-Splat ranks (row f2: bev_pool_v2 at the f8 shape)
+def make_lss_ranks(n_cams=6, D=96, H=16, W=44, grid=128, cell=0.8, depth=(1.0, 65.0), fx=560.0 / 16.0):
+    """(ranks_depth, ranks_feat, ranks_bev) of a Lift-Splat frustum like the reference's LSSViewTransformer builds them
+    (necks/view_transformer_racformer.py voxel_pooling_prepare_v2: every (cam, depth bin, h, w) frustum point lands in one BEV
+    cell or outside the grid; points sorted by cell): ring rig of n_cams pinhole cameras at the feature stride 16."""
+    d = depth[0] + (np.arange(D) + 0.5) * (depth[1] - depth[0]) / D
+    u = (np.arange(W) + 0.5 - W / 2.0) / fx
+    cams = 2 * np.pi * np.arange(n_cams) / n_cams
+    dd, uu, cc = np.meshgrid(d, u, cams, indexing="ij")                  # [D, W, N]
+    x = dd * np.cos(cc) + dd * uu * np.sin(cc)
+    y = dd * np.sin(cc) - dd * uu * np.cos(cc)
+    ix, iy = np.floor(x / cell + grid / 2).astype(np.int64), np.floor(y / cell + grid / 2).astype(np.int64)
+    ok = (ix >= 0) & (ix < grid) & (iy >= 0) & (iy < grid)               # [D, W, N]
+    n, dbin, h, w = np.meshgrid(np.arange(n_cams), np.arange(D), np.arange(H), np.arange(W), indexing="ij")
+    keep = ok[dbin, w, n]
+    rd = (((n * D + dbin) * H + h) * W + w)[keep]
+    rf = ((n * H + h) * W + w)[keep]
+    rb = (iy[dbin, w, n] * grid + ix[dbin, w, n])[keep]
+    order = np.argsort(rb, kind="stable")
+    return tuple(torch.from_numpy(a[order].astype(np.int32)) for a in (rd, rf, rb))
+
+
 # ------------------------------------------------------------------ queries
 def head_query_grid(cfg: RigConfig):
     """Polar query grid of RaCFormer_head._init_layers / generate_points

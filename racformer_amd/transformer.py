@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
 from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add_ln, bev_sampling_fused, bev_sampling_multi_fused, box_prep,
+                    quantize_values_i16,
                     generator_fused, gru_gate_fused, layer_boundary_fused, mixing_fused, outproj_fused, pack_conv3x3_weight,
                     pack_gemm_split_weight,
                     pe_head, refine_fused, row_gemm,
@@ -890,6 +891,10 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         self._carry = None
         # radar stream: value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack)
         self.compose_radar_value = True
+        # storage of the two hoisted BEV value streams: "f32" (default, the reference's), or "i16" -- int16 mantissas with one
+        # power-of-two scale per (pixel, head) block of 64 channels (csrc/quant.hip): half the bytes the BEV kernel gathers;
+        # opt-in, parity measured under the same criteria as fp32 (tests/test_lowprec_storage_gpu.py)
+        self.value_storage = "f32"
         self._pack_cache = {}
 
     def _cached(self, key, params, fn):
@@ -1031,7 +1036,17 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # the wide Linear on the same split-precision kernel as the generator (it reads the same f16 image of norm1's output)
         wide_img = self._cached("wide_img", [w], lambda: pack_gemm_split_weight(w)) if packs and self.own_generator else (None, None)
         out_proj_split = None if packs else self._cached("out_proj_split", [mix.out_proj.weight], mix.split_out_proj)
-        return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw,
+        value_scales = None
+        if self.value_storage == "i16":
+            if not (self.fused and radar_value.is_cuda and radar_value.dtype == torch.float32 and lss_value.dtype == torch.float32
+                    and radar_value.shape[-1] == 64 and lss_value.shape[-1] == 64 and radar_hw == lss_hw):
+                raise RuntimeError("value_storage='i16' needs the fused plan and two fp32 value streams of equal shape with 64 channels per head")
+            radar_value, rsc = quantize_values_i16(radar_value.contiguous())
+            lss_value, lsc = quantize_values_i16(lss_value.contiguous())
+            value_scales = (rsc, lsc)
+        elif self.value_storage != "f32":
+            raise RuntimeError(f"value_storage must be 'f32' or 'i16', got {self.value_storage!r}")
+        return dict(radar_value=radar_value, radar_hw=radar_hw, lss_value=lss_value, lss_hw=lss_hw, value_scales=value_scales,
                     wide_w=w, wide_b=b, wide_widths=widths, wide_img=wide_img, out_proj_split=out_proj_split, split_packs=packs,
                     sasa_w=sasa_w, bev_owt=bev_owt, bev_ob=bev_ob, c0r0_w=c0r0_w, c0r0_b=c0r0_b,
                     fusion_k=kslices[0], ffn2_k=kslices[1])
@@ -1097,7 +1112,9 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             # the first one's drain
             bev_sampling_multi_fused([(prepared["radar_value"], r_off, r_ray, r_sc, r_qu), (prepared["lss_value"], l_off, l_ray, l_sc, l_qu)],
                                      prepared["radar_hw"], qb, time_diff, rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num,
-                                     rb.pc_range, d_region, table, bev)
+                                     rb.pc_range, d_region, table, bev, value_scales=prepared.get("value_scales"))
+        elif prepared.get("value_scales") is not None:
+            raise RuntimeError("value_storage='i16' is served by the two-stream launch only")
         else:
             bev_sampling_fused(prepared["radar_value"], prepared["radar_hw"], qb, r_off, r_ray, r_sc, r_qu, time_diff,
                                rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num, rb.pc_range, d_region,

@@ -147,6 +147,60 @@ def test_bev_sampling_fused(cfg):
 
 
 @pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])
+def test_bev_sampling_int16_block_value_streams(cfg):
+    """Opt-in 16-bit block storage of the BEV value streams (csrc/quant.hip, rac_bev_sampling_multi_q16_fwd).  (1) The format: q * scale
+    reproduces every value to 2^-15 of its (pixel, head) block's largest one, the scale is the power of two the format defines,
+    zero blocks stay zero -- checked against the definition restated here in torch on the host.  (2) The kernel: both streams of a
+    layer gathered from the int16 streams equal the ORACLE's deformable attention + frame fusion evaluated on the dequantised
+    values (the scale folded into the tap weights changes nothing but the rounding order)."""
+    from racformer_amd.fused import bev_sampling_multi_fused, box_prep, quantize_values_i16
+    tr, sd, qb, qf, metas = _setup(cfg, 33, 34)
+    layer = tr.decoder.decoder_layer
+    d_region = cfg.d_region_list[2]
+    T, heads, B, Q = cfg.num_frames, 4, cfg.batch, cfg.num_query
+    H, W = cfg.bev_hw
+    g = torch.Generator().manual_seed(5)
+    td = R.time_diff_from_metas(syn.make_img_metas(cfg), cfg.batch, cfg.num_cams)
+    streams, scales, deq, outs_ref = [], [], [], []
+    for name in ("sampling_radar_bev", "sampling_lss_bev"):
+        v = torch.randn(B * T, H * W, heads, 64, generator=g)
+        v = v * torch.exp2(torch.randint(-20, 12, (B * T, H * W, heads, 1), generator=g).float())      # blocks over 32 octaves
+        v[0, :7] = 0.0                                                                                 # some all-zero blocks
+        q, sc = quantize_values_i16(v.to(DEV))
+        torch.cuda.synchronize()
+        m = v.abs().amax(-1)
+        want_sc = torch.exp2(torch.frexp(m.clamp_min(1e-30))[1].float() - 1.0 - 14.0)      # m = mant * 2^e, mant in [0.5, 1): floor(log2 m) = e - 1
+        assert torch.equal(sc.cpu()[m > 0], want_sc[m > 0]), name
+        dq = q.cpu().float() * sc.cpu()[..., None]
+        assert (dq - v).abs().max().item() == 0.0 or bool(((dq - v).abs() <= m[..., None] * 2.0 ** -15 * 1.0001).all()), name
+        assert float(dq[0, :7].abs().max()) == 0.0 and int(q.abs().max()) <= 32767
+        mod = getattr(layer, name)
+        with torch.no_grad():
+            lin = (mod.sampling_offset(qf.to(DEV)), mod.ray_points_offset(qf.to(DEV)), mod.scale_weights(qf.to(DEV)),
+                   mod.attention.bev_queue_weight(qf.to(DEV)))
+        streams.append((q,) + tuple(x.contiguous() for x in lin))
+        scales.append(sc)
+        # the oracle on the dequantised stream: keypoints -> per-frame deformable attention -> frame softmax fusion
+        loc, sw = R.bev_keypoints(sd, name, qb, qf, td, d_region, cfg)
+        P = loc.shape[-2]
+        loc7 = loc.view(B, Q, heads, T, 1, P, 2).permute(3, 0, 1, 2, 4, 5, 6).reshape(B * T, Q, heads, 1, P, 2)
+        aw = sw.view(B, Q, heads, T, 1, P).permute(3, 0, 1, 2, 4, 5).reshape(B * T, Q, heads, 1, P)
+        o = R.msda(dq.contiguous(), [[H, W]], [0], loc7.contiguous(), aw.contiguous()).permute(1, 2, 0).reshape(Q, 256, B, T)
+        qw = R._lin(sd, name + ".attention.bev_queue_weight", qf).permute(1, 0, 2).reshape(Q, 1, B, T)
+        outs_ref.append(torch.sum(o * torch.softmax(qw, dim=-1), dim=-1).permute(2, 0, 1))
+    out = torch.empty(2, B, Q, 256, device=DEV)
+    qbd = qb.to(DEV).contiguous()
+    rb = layer.sampling_radar_bev
+    with torch.no_grad():
+        bev_sampling_multi_fused(streams, (H, W), qbd, metas[0]["time_diff"], rb.num_frames, rb.num_heads, rb.num_points, rb.depth_num,
+                                 rb.pc_range, d_region, box_prep(qbd, list(cfg.pc_range)), out, value_scales=scales)
+    torch.cuda.synchronize()
+    for i in range(2):
+        scale_ = float(outs_ref[i].abs().max())
+        assert (out[i].cpu() - outs_ref[i]).abs().max().item() < 2e-5 * max(scale_, 1.0), (i, (out[i].cpu() - outs_ref[i]).abs().max().item(), scale_)
+
+
+@pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])
 def test_sasa_fused(cfg):
     tr, sd, qb, qf, metas = _setup(cfg, 41, 42)
     sa = tr.decoder.decoder_layer.self_attn

@@ -134,13 +134,6 @@ __device__ __forceinline__ rac_f4 bev_tap<unsigned short>(__amdgpu_buffer_rsrc_t
                     __uint_as_float(r.y & 0xffff0000u)};
 }
 
-template <>
-__device__ __forceinline__ rac_f4 bev_tap<short>(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
-{
-    const bev_u2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);    // 4 x int16 mantissas (the block's scale rides in the tap weight)
-    return (rac_f4){(float)(short)(r.x & 0xffffu), (float)((int)r.x >> 16), (float)(short)(r.y & 0xffffu), (float)((int)r.y >> 16)};
-}
-
 // per-(t,p) half of the keypoint chain for B==1: warp the T-invariant base point, polar jitter.
 __device__ __forceinline__ void bev_warp(const BevArgs &a, float px, float py, float vx, float vy, float td,
                                          float doff, float *loc2)
@@ -168,17 +161,23 @@ __device__ __forceinline__ float bev_wave_sum(float v)
     return v;
 }
 
-template <typename FT>
+// GL = lanes of a group (one group gathers one tap row per load): 16 lanes x 4 channels for the 4-byte and bf16 streams; 8 lanes x 8
+// channels (16 bytes of int16 per lane) for the int16 block storage -- the texture path's cost is per wave-instruction (address work for
+// 64 lanes) at least as much as per byte: with 16 lanes per tap the int16 stream halved the bytes at the same number of tap
+// instructions and bought 9 % (80 -> 73 us); with 8 lanes per tap a wave-instruction covers 8 tap rows instead of 4.
+template <typename FT, int GL>
 __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const BevArgs a)
 {
+    constexpr int TSN = 64 / GL;      // groups per item (= per wave): keypoint subsets
+    static_assert((GL == 16 && sizeof(FT) >= 2) || (GL == 8 && sizeof(FT) == 2), "16 lanes x 4 channels, or 8 lanes x 8 two-byte channels");
     extern __shared__ float smem[];
     BEV_STAMP(0);
     const BevStream &s = a.s[blockIdx.y];
     const int tid = threadIdx.x;
-    const int c4 = tid & 15, grp = tid >> 4;
-    const int k = grp >> 2, ts = grp & 3;       // item within the workgroup, point subset
+    const int c4 = tid & (GL - 1), grp = tid / GL;
+    const int k = grp / TSN, ts = grp % TSN;    // item within the workgroup (= wave), keypoint subset
     const int T = a.T, P = a.P, TP = a.T * a.P, D = a.D;
-    const int npp = (P + BEV_TS - 1) / BEV_TS;  // points of a subset per frame (the last subsets may hold one less)
+    const int npp = (P + BEV_TS - 1) / BEV_TS;  // GL = 16: points of a subset per frame (the last subsets may hold one less)
     const int Lg = a.list_len;                  // entries of a group's tap list: T * npp rounded up to BEV_U
 
     const int per_b = a.Q * a.heads;
@@ -196,9 +195,9 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
     // tap lists, one per 16-lane group and in the order the group walks them (frame-major): [GI][TS][Lg][8] =
     // 4 tap byte offsets into the value buffer (BEV_TAP_OUTSIDE = outside the map) + 4 tap weights
     float *stab = smem;
-    float *spart = stab + BEV_GI * BEV_TS * Lg * 8;  // [GI][TS][64] partial sums
+    float *spart = stab + BEV_GI * TSN * Lg * 8;     // [GI][TSN][64] partial sums
     const int Tw = a.B > 1 ? T : 1;            // B > 1: the point weights depend on the frame (paired batch, quirk Q2)
-    float *sattn = spart + BEV_GI * BEV_TS * 64;     // [GI][Tw][P]
+    float *sattn = spart + BEV_GI * TSN * 64;        // [GI][Tw][P]
     float *sq = sattn + BEV_GI * Tw * P;       // [GI][T]
     float *sbase = sq + BEV_GI * T;            // [GI][P][2]  T-invariant base points (B==1)
     float *sdoff = sbase + BEV_GI * P * 2;     // [GI][D]
@@ -207,7 +206,7 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
 
     // list slots no keypoint fills (P not a multiple of 4, T * npp not a multiple of BEV_U): outside, weight 0
     if (a.list_holes) {
-        for (int i = tid; i < BEV_GI * BEV_TS * Lg * 2; i += 256) {
+        for (int i = tid; i < BEV_GI * TSN * Lg * 2; i += 256) {
             const unsigned fill = (i & 1) ? 0u : BEV_TAP_OUTSIDE;
             reinterpret_cast<bev_u4 *>(stab)[i] = (bev_u4){fill, fill, fill, fill};
         }
@@ -314,8 +313,11 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
             const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
             // byte offset of (frame b*T+t, pixel 0, head h, channel 0) in the value buffer
             const unsigned fbase = ((unsigned)(b * T + t) * (unsigned)(H * W) * (unsigned)a.heads + (unsigned)h) * (unsigned)(64 * sizeof(FT));
-            float *e = stab + (((kk * BEV_TS + (p & (BEV_TS - 1))) * Lg) + t * npp + (p >> 2)) * 8;
+            // GL = 16: subset = p & 3, slot = t * npp + (p >> 2) (frame-major inside a subset).  GL = 8: the item's T * P keypoints dealt
+            // round-robin to its eight groups in frame-major order (subset = r & 7, slot = r >> 3 with r = t * P + p)
             static_assert(BEV_TS == 4, "point subset = p & 3, slot = p >> 2");
+            float *e = GL == 16 ? stab + (((kk * TSN + (p & (BEV_TS - 1))) * Lg) + t * npp + (p >> 2)) * 8
+                                : stab + (((kk * TSN + (r & (TSN - 1))) * Lg) + r / TSN) * 8;
             bev_u4 off;
             off.x = t_ok && l_ok ? fbase + (unsigned)(h_low * W + w_low) * pix_bytes : BEV_TAP_OUTSIDE;
             off.y = t_ok && r_ok ? fbase + (unsigned)(h_low * W + w_high) * pix_bytes : BEV_TAP_OUTSIDE;
@@ -347,47 +349,101 @@ __global__ __launch_bounds__(256, BEV_OCC) void bev_sampling_d64_kernel(const Be
     // phase C: a group walks its list (frame-major: the chip works on (nearly) one frame at a time, which the L2s /
     // Infinity Cache hold better than all of them), BEV_U keypoints = 4 * BEV_U taps in flight.  Per tap: one add for
     // the lane's channel offset, one buffer load, two packed FMAs -- the gather runs at the L1 rate, not the VALU's.
-    rac_acc4 acc4 = rac_acc4_zero();
     const bool live = k < nitems;
-    if (live) {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.value), 0, a.value_bytes, 0x00020000);
-        const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
-        const float *e = stab + (k * BEV_TS + ts) * Lg * 8;          // same address for the 16 lanes of the group
-        for (int j0 = 0; j0 < Lg; j0 += BEV_U) {
-            rac_f4 v[BEV_U][4], tw[BEV_U];
+    if constexpr (GL == 16) {
+        rac_acc4 acc4 = rac_acc4_zero();
+        if (live) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.value), 0, a.value_bytes, 0x00020000);
+            const unsigned lane_off = (unsigned)(c4 * 4 * sizeof(FT));
+            const float *e = stab + (k * TSN + ts) * Lg * 8;          // same address for the 16 lanes of the group
+            for (int j0 = 0; j0 < Lg; j0 += BEV_U) {
+                rac_f4 v[BEV_U][4], tw[BEV_U];
 #pragma unroll
-            for (int u = 0; u < BEV_U; ++u) {
-                const bev_u4 o = *reinterpret_cast<const bev_u4 *>(e + (j0 + u) * 8);
-                tw[u] = *reinterpret_cast<const rac_f4 *>(e + (j0 + u) * 8 + 4);
-                v[u][0] = bev_tap<FT>(rsrc, o.x + lane_off);
-                v[u][1] = bev_tap<FT>(rsrc, o.y + lane_off);
-                v[u][2] = bev_tap<FT>(rsrc, o.z + lane_off);
-                v[u][3] = bev_tap<FT>(rsrc, o.w + lane_off);
-            }
+                for (int u = 0; u < BEV_U; ++u) {
+                    const bev_u4 o = *reinterpret_cast<const bev_u4 *>(e + (j0 + u) * 8);
+                    tw[u] = *reinterpret_cast<const rac_f4 *>(e + (j0 + u) * 8 + 4);
+                    v[u][0] = bev_tap<FT>(rsrc, o.x + lane_off);
+                    v[u][1] = bev_tap<FT>(rsrc, o.y + lane_off);
+                    v[u][2] = bev_tap<FT>(rsrc, o.z + lane_off);
+                    v[u][3] = bev_tap<FT>(rsrc, o.w + lane_off);
+                }
 #pragma unroll
-            for (int u = 0; u < BEV_U; ++u) {
-                const float w4[4] = {tw[u].x, tw[u].y, tw[u].z, tw[u].w};
+                for (int u = 0; u < BEV_U; ++u) {
+                    const float w4[4] = {tw[u].x, tw[u].y, tw[u].z, tw[u].w};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    rac_tap_fma(acc4, v[u][c].x, v[u][c].y, v[u][c].z, v[u][c].w, w4[c]);
+                    for (int c = 0; c < 4; ++c) {
+                        rac_tap_fma(acc4, v[u][c].x, v[u][c].y, v[u][c].z, v[u][c].w, w4[c]);
+                    }
                 }
             }
         }
-    }
-    rac_f4 acc;
-    rac_acc4_get(acc4, acc.x, acc.y, acc.z, acc.w);
-    BEV_STAMP(3);
-    // phase D: fixed-order sum of the four point subsets (deterministic, no atomics)
-    *reinterpret_cast<rac_f4 *>(spart + (k * BEV_TS + ts) * 64 + c4 * 4) = acc;
-    __syncthreads();
-    if (live && ts == 0) {
-        rac_f4 o = acc;
+        rac_f4 acc;
+        rac_acc4_get(acc4, acc.x, acc.y, acc.z, acc.w);
+        BEV_STAMP(3);
+        // phase D: fixed-order sum of the four point subsets (deterministic, no atomics)
+        *reinterpret_cast<rac_f4 *>(spart + (k * TSN + ts) * 64 + c4 * 4) = acc;
+        __syncthreads();
+        if (live && ts == 0) {
+            rac_f4 o = acc;
 #pragma unroll
-        for (int u = 1; u < BEV_TS; ++u) {
-            const rac_f4 pz = *reinterpret_cast<const rac_f4 *>(spart + (k * BEV_TS + u) * 64 + c4 * 4);
-            o.x += pz.x; o.y += pz.y; o.z += pz.z; o.w += pz.w;
+            for (int u = 1; u < TSN; ++u) {
+                const rac_f4 pz = *reinterpret_cast<const rac_f4 *>(spart + (k * TSN + u) * 64 + c4 * 4);
+                o.x += pz.x; o.y += pz.y; o.z += pz.z; o.w += pz.w;
+            }
+            *reinterpret_cast<rac_f4 *>(s.out + ((size_t)b * per_b + (i0 + k)) * 64 + c4 * 4) = o;
         }
-        *reinterpret_cast<rac_f4 *>(s.out + ((size_t)b * per_b + (i0 + k)) * 64 + c4 * 4) = o;
+    } else {
+        // int16 block storage, 8 lanes per tap row: one 16-byte load = this lane's 8 channels of the tap
+        float accv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            accv[c] = 0.f;
+        if (live) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.value), 0, a.value_bytes, 0x00020000);
+            const unsigned lane_off = (unsigned)(c4 * 8 * sizeof(FT));
+            const float *e = stab + (k * TSN + ts) * Lg * 8;
+            for (int j0 = 0; j0 < Lg; j0 += BEV_U) {
+                bev_u4 v[BEV_U][4];
+                rac_f4 tw[BEV_U];
+#pragma unroll
+                for (int u = 0; u < BEV_U; ++u) {
+                    const bev_u4 o = *reinterpret_cast<const bev_u4 *>(e + (j0 + u) * 8);
+                    tw[u] = *reinterpret_cast<const rac_f4 *>(e + (j0 + u) * 8 + 4);
+                    v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + lane_off, 0, 0);
+                    v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + lane_off, 0, 0);
+                    v[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + lane_off, 0, 0);
+                    v[u][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + lane_off, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < BEV_U; ++u) {
+                    const float w4[4] = {tw[u].x, tw[u].y, tw[u].z, tw[u].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned d[4] = {v[u][c].x, v[u][c].y, v[u][c].z, v[u][c].w};
+#pragma unroll
+                        for (int h2 = 0; h2 < 4; ++h2) {
+                            accv[2 * h2] = __builtin_fmaf((float)(short)(d[h2] & 0xffffu), w4[c], accv[2 * h2]);
+                            accv[2 * h2 + 1] = __builtin_fmaf((float)((int)d[h2] >> 16), w4[c], accv[2 * h2 + 1]);
+                        }
+                    }
+                }
+            }
+        }
+        BEV_STAMP(3);
+        // phase D: fixed-order sum of the eight keypoint subsets
+        *reinterpret_cast<rac_f4 *>(spart + (k * TSN + ts) * 64 + c4 * 8) = (rac_f4){accv[0], accv[1], accv[2], accv[3]};
+        *reinterpret_cast<rac_f4 *>(spart + (k * TSN + ts) * 64 + c4 * 8 + 4) = (rac_f4){accv[4], accv[5], accv[6], accv[7]};
+        __syncthreads();
+        if (live && ts == 0) {
+#pragma unroll
+            for (int u = 1; u < TSN; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    accv[c] += spart[(k * TSN + u) * 64 + c4 * 8 + c];
+            float *op = s.out + ((size_t)b * per_b + (i0 + k)) * 64 + c4 * 8;
+            *reinterpret_cast<rac_f4 *>(op) = (rac_f4){accv[0], accv[1], accv[2], accv[3]};
+            *reinterpret_cast<rac_f4 *>(op + 4) = (rac_f4){accv[4], accv[5], accv[6], accv[7]};
+        }
     }
     BEV_STAMP(4);
 #ifdef BEV_STAMPS
@@ -425,8 +481,9 @@ static int bev_launch(int nstreams, const void *const *values, const float *cons
     RAC_CHECK_ARG((dtype == RAC_I16) == (vscales != nullptr), "rac_bev_sampling_fwd: int16 value streams come with their scale tables (and only they)");
     const int P = NP * D;
     const int npp = (P + BEV_TS - 1) / BEV_TS;
-    const int list_len = (T * npp + BEV_U - 1) / BEV_U * BEV_U;
-    const size_t lds = ((size_t)BEV_GI * BEV_TS * list_len * 8 + (size_t)BEV_GI * BEV_TS * 64 + (size_t)BEV_GI * (B > 1 ? T : 1) * P +
+    const int tsn = dtype == RAC_I16 ? 8 : BEV_TS;                       // groups per item (bev_sampling_d64_kernel's TSN)
+    const int list_len = dtype == RAC_I16 ? ((T * P + 7) / 8 + BEV_U - 1) / BEV_U * BEV_U : (T * npp + BEV_U - 1) / BEV_U * BEV_U;
+    const size_t lds = ((size_t)BEV_GI * tsn * list_len * 8 + (size_t)BEV_GI * tsn * 64 + (size_t)BEV_GI * (B > 1 ? T : 1) * P +
                         (size_t)BEV_GI * T + (size_t)BEV_GI * P * 2 + (size_t)BEV_GI * BEV_MAX_DEPTH + (size_t)BEV_GI * 2 + (size_t)T) * sizeof(float);
     RAC_CHECK_ARG(lds <= 64 * 1024, "rac_bev_sampling_fwd: T*P=%d too large for the LDS staging", T * P);
     const size_t value_bytes = (size_t)B * T * H * W * heads * 64 * (dtype == RAC_F32 ? 4 : 2);   // (bf16 and int16: 2 bytes)
@@ -460,16 +517,16 @@ static int bev_launch(int nstreams, const void *const *values, const float *cons
     a.blocks_per_b = (Q * heads + BEV_GI - 1) / BEV_GI;
     a.value_bytes = (unsigned)value_bytes;
     a.list_len = list_len;
-    a.list_holes = (P % BEV_TS != 0 || list_len != T * npp) ? 1 : 0;
+    a.list_holes = dtype == RAC_I16 ? (list_len * 8 != T * P ? 1 : 0) : ((P % BEV_TS != 0 || list_len != T * npp) ? 1 : 0);
     a.xcd_remap = 1;
     const dim3 grid(B * a.blocks_per_b, nstreams);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RAC_F32)
-        hipLaunchKernelGGL(bev_sampling_d64_kernel<float>, grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((bev_sampling_d64_kernel<float, 16>), grid, dim3(256), lds, st, a);
     else if (dtype == RAC_I16)
-        hipLaunchKernelGGL(bev_sampling_d64_kernel<short>, grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((bev_sampling_d64_kernel<short, 8>), grid, dim3(256), lds, st, a);
     else
-        hipLaunchKernelGGL(bev_sampling_d64_kernel<unsigned short>, grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((bev_sampling_d64_kernel<unsigned short, 16>), grid, dim3(256), lds, st, a);
     return rac_launch_status("rac_bev_sampling_fwd");
 }
 

@@ -197,7 +197,9 @@ def test_bev_sampling_int16_block_value_streams(cfg):
     torch.cuda.synchronize()
     for i in range(2):
         scale_ = float(outs_ref[i].abs().max())
-        assert (out[i].cpu() - outs_ref[i]).abs().max().item() < 2e-5 * max(scale_, 1.0), (i, (out[i].cpu() - outs_ref[i]).abs().max().item(), scale_)
+        # (white-noise blocks over 32 octaves: an ulp of a pixel coordinate moves a 640-tap sum by ~3e-5 of its magnitude -- the two
+        #  sides compute the coordinates with different libm; the quantisation itself does not enter: both sides read q * scale)
+        assert (out[i].cpu() - outs_ref[i]).abs().max().item() < 1e-4 * max(scale_, 1.0), (i, (out[i].cpu() - outs_ref[i]).abs().max().item(), scale_)
 
 
 @pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])

@@ -15,7 +15,12 @@ BASELINE configs 3 / 5 name bf16.  Round 3 measured bf16 storage only on the ran
      1e-3) -- but on that rig's chaotic seed (decoder_f8_s1.npz, where fp32 itself has 1 / 8 queries over 1e-3 in layers
      4 / 5) it has 8 / 33, beyond the tail budget the fp32 path is held to (4 / 12).  f16 value streams would halve the
      bytes through the CU's texture path that bound the BEV kernel, so the result is recorded precisely; the
-     default keeps fp32 because one committed fixture fails with it."""
+     default keeps fp32 because one committed fixture fails with it.
+(iii) int16 BLOCK storage of the value streams (one power-of-two scale per (pixel, head) block of 64 channels, 14-15 significant
+     bits relative to the block's largest value: csrc/quant.hip) -- the format that is actually built
+     (`decoder_layer.value_storage = "i16"`, rac_bev_sampling_multi_q16_fwd): literal on both init rigs and inside the SAME
+     tail budget as fp32 on the random rig including its chaotic seed (emulated: 0/0/0/0/1/7 queries over 1e-3 against fp32's
+     0/0/0/0/1/8).  `test_decoder_int16_block_value_streams_*` run the REAL kernels under the fp32 path's own criteria."""
 import os
 
 import numpy as np
@@ -81,3 +86,29 @@ def test_random_rig_f16_value_streams_measured():
     assert all(a <= b for a, b in zip(fp32["queries_over_1e-3"], TAIL_QUERIES))
     assert vh["queries_over_1e-3"][5] > TAIL_QUERIES[5] and max(vh["box_max"]) < 5e-2, \
         "f16 value streams now stay inside the tail budget on the chaotic seed: make them the BEV kernel's storage (DESIGN 3.2)"
+
+
+# ------------------------------------------------------------------------------------------------ (iii) the built format
+from parity import ARGMAX_MARGIN_INIT_RIG, decoder_parity, run_with_reference_views  # noqa: E402
+from test_parity_gpu import run_decoder_gpu  # noqa: E402
+
+
+@pytest.mark.parametrize("name,cfg", [("decoder_f8_init.npz", syn.F8), ("decoder_f8_3cam_init.npz", syn.F8_3CAM)])
+def test_decoder_int16_block_value_streams_init_rig_literal(golden_dir, name, cfg):
+    """The product decoder with `value_storage = "i16"` (quantiser + int16 BEV kernel) on the reference-initialised rig:
+    north_star's criterion literally, as for fp32 storage."""
+    g = np.load(os.path.join(golden_dir, name))
+    seed, wseed = int(g["seed"]), int(g["weight_seed"])
+    (cls, box, _), _ = run_with_reference_views(
+        lambda force: run_decoder_gpu(cfg, seed, wseed, force, rig=(g, golden_dir), value_storage="i16"), g["views"], name + " (i16 values)")
+    decoder_parity(cls, box, g["cls"], g["box"], what=name + " (i16 values)", tail_budget=None, argmax_margin=ARGMAX_MARGIN_INIT_RIG)
+
+
+@pytest.mark.parametrize("name,cfg", [("decoder_f8.npz", syn.F8), ("decoder_f8_s1.npz", syn.F8), ("decoder_f8_3cam_s1.npz", syn.F8_3CAM)])
+def test_decoder_int16_block_value_streams_random_rig_same_budget(golden_dir, name, cfg):
+    """... and on the random-everything rig, chaotic seeds included, under the SAME tail budget and tie rule as the fp32 path."""
+    g = np.load(os.path.join(golden_dir, name))
+    seed, wseed = int(g["seed"]), int(g["weight_seed"])
+    (cls, box, _), _ = run_with_reference_views(lambda force: run_decoder_gpu(cfg, seed, wseed, force, value_storage="i16"), g["views"],
+                                                name + " (i16 values)")
+    decoder_parity(cls, box, g["cls"], g["box"], what=name + " (i16 values)")

@@ -576,8 +576,8 @@ extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias
     a.bias = bias; a.pixel_bias = pixel_bias; a.amax = amax; a.out = out;
     a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = 1;
     const int lds = 2 * CV_STAGE_U4 * 16;
-    if (rac_first_use_on_device(RAC_ATTR_CONV3X3))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_CONV3X3, reinterpret_cast<const void *>(conv3x3_f16x3_kernel<false>), (int)(lds)))
+        return rc_attr;
     hipLaunchKernelGGL(conv3x3_f16x3_kernel<false>, dim3((unsigned)(N * ((H * W + CV_TM - 1) / CV_TM))), dim3(512), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_conv3x3_fwd");
 }
@@ -600,8 +600,8 @@ extern "C" int rac_fpn_conv_fwd(const void *xs, const void *ws, const float *bia
     a.bias = bias; a.pixel_bias = nullptr; a.amax = amax; a.out = out;
     a.N = num_images; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = num_cams;
     const int lds = 2 * CV_STAGE_U4 * 16;
-    if (rac_first_use_on_device(RAC_ATTR_FPN_CONV))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_FPN_CONV, reinterpret_cast<const void *>(conv3x3_f16x3_kernel<true>), (int)(lds)))
+        return rc_attr;
     hipLaunchKernelGGL(conv3x3_f16x3_kernel<true>, dim3((unsigned)(num_images * ((H * W + CV_TM - 1) / CV_TM))), dim3(512), lds,
                        (hipStream_t)stream, a);
     return rac_launch_status("rac_fpn_conv_fwd");
@@ -625,8 +625,8 @@ extern "C" int rac_conv3x3s2_fwd(const void *xs, const void *ws, const float *bi
     a.bias = bias; a.amax = amax; a.out = out;
     a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.chunks_total = Cin_image / 32; a.out_ctotal = out_channels_total; a.w_alpha = w_alpha;
     const int lds = 2 * (S2_TM * 8 + 512) * 16;
-    if (rac_first_use_on_device(RAC_ATTR_CONV3X3S2))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3s2_c64_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_CONV3X3S2, reinterpret_cast<const void *>(conv3x3s2_c64_f16x3_kernel), (int)(lds)))
+        return rc_attr;
     hipLaunchKernelGGL(conv3x3s2_c64_f16x3_kernel, dim3((unsigned)(N * ((H / 2) * (W / 2) / S2_TM))), dim3(S2_THREADS), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_conv3x3s2_fwd");
 }

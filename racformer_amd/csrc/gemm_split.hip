@@ -457,9 +457,8 @@ static int gs_launch(GemmSplitArgs &g, int tiles_per_wg, hipStream_t st, const c
     g.m16 = (g.M + 15) / 16;
     g.tiles_per_wg = tiles_per_wg;
     const int ntiles = g.tiles_x * g.tiles_w * g.slices;
-    if (rac_first_use_on_device(RAC_ATTR_GEMM_SPLIT))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GS_STAGES * GS_STAGE);
+    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_GEMM_SPLIT, reinterpret_cast<const void *>(gemm_split_kernel), (int)(GS_STAGES * GS_STAGE)))
+        return rc_attr;
     hipLaunchKernelGGL(gemm_split_kernel, dim3((ntiles + tiles_per_wg - 1) / tiles_per_wg), dim3(768), GS_STAGES * GS_STAGE, st, g);
     return rac_launch_status(what);
 }
@@ -503,9 +502,8 @@ extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const
         chunks = chunks > max_chunks ? max_chunks : chunks;
         a.rows_per_wg = ((M + chunks - 1) / chunks + GW_ROWS - 1) / GW_ROWS * GW_ROWS;
         chunks = (M + a.rows_per_wg - 1) / a.rows_per_wg;
-        if (rac_first_use_on_device(RAC_ATTR_GENERATOR))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(generator_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      GW_STAGES * GW_STAGE);
+        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_GENERATOR, reinterpret_cast<const void *>(generator_ws_kernel), (int)(GW_STAGES * GW_STAGE)))
+        return rc_attr;
         hipLaunchKernelGGL(generator_ws_kernel, dim3(fblocks, chunks), dim3(512), GW_STAGES * GW_STAGE, (hipStream_t)stream, a);
         return rac_launch_status("rac_generator_fwd");
     }

@@ -551,14 +551,14 @@ extern "C" int rac_mixing_fwd(const float *x, const float *params, float param_s
     a.out_split = reinterpret_cast<_Float16 *>(out_split); a.split_scale = split_scale; a.param_scale = param_scale;
     a.nq = num_query; a.G = groups; a.P = in_points; a.ld_params = ld_params; a.eps = eps;
     const size_t lds = (size_t)MIX_LDS_FLOATS * sizeof(float);
-    if (rac_first_use_on_device(RAC_ATTR_MIXING_F32))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mixing_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_MIXING_F32, reinterpret_cast<const void *>(mixing_c64_kernel), (int)((int)lds)))
+        return rc_attr;
     if (mfma_mode == RAC_MIX_F16X3) {
         static_assert(3 * MIXH_LDS_BYTES <= 160 * 1024, "three workgroups per CU");
         static_assert(MIXH_REGION_BYTES >= MIX_OUT * MIX_C * 4, "output tile must fit the shared region");
         static_assert(MIXH_SS >= MIX_PMAX + 8 && (MIXH_SS * 2) % 16 == 0, "S row stride");
-        if (rac_first_use_on_device(RAC_ATTR_MIXING_F16))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mixing_c64_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MIXH_LDS_BYTES);
+        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_MIXING_F16, reinterpret_cast<const void *>(mixing_c64_f16x3_kernel), (int)((int)MIXH_LDS_BYTES)))
+        return rc_attr;
         hipLaunchKernelGGL(mixing_c64_f16x3_kernel, dim3(num_query * groups), dim3(256), MIXH_LDS_BYTES, (hipStream_t)stream, a);
         return rac_launch_status("rac_mixing_fwd");
     }

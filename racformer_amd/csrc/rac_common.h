@@ -9,9 +9,9 @@
 
 void rac_set_error(const char *fmt, ...);
 
-// Function attributes (the dynamic-LDS limit) are per device: true the first time kernel slot `id` (0..63, one per kernel that
-// raises its limit) is asked for on the CURRENT device, from any thread.  (capi.cpp)
-bool rac_first_use_on_device(int id);
+// Function attributes (the dynamic-LDS limit) are per device: sets it for kernel slot `id` (0..63, one per kernel that raises its
+// limit) on the CURRENT device unless an earlier call already did, from any thread; 0 or the HIP error (rac_last_error set).  (capi.cpp)
+int rac_set_dynamic_lds_once(int id, const void *func, int bytes);
 enum { RAC_ATTR_GEMM_SPLIT = 0, RAC_ATTR_GENERATOR, RAC_ATTR_CONV3X3, RAC_ATTR_CONV3X3S2, RAC_ATTR_MIXING_F32, RAC_ATTR_MIXING_F16,
        RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV };
 

@@ -211,8 +211,8 @@ extern "C" int rac_value_proj_fwd(const float *x, const void *w_image, float w_a
     ppw = (ppw + VP_ROWS - 1) / VP_ROWS * VP_ROWS;
     a.pixels_per_wg = (int)ppw;
     const unsigned grid = (unsigned)((a.M + ppw - 1) / ppw);
-    if (rac_first_use_on_device(RAC_ATTR_VALUE_PROJ))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(value_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VP_LDS);
+    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_VALUE_PROJ, reinterpret_cast<const void *>(value_proj_kernel), (int)(VP_LDS)))
+        return rc_attr;
     hipLaunchKernelGGL(value_proj_kernel, dim3(grid), dim3(512), VP_LDS, (hipStream_t)stream, a);
     return rac_launch_status("rac_value_proj_fwd");
 }

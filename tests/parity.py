@@ -27,7 +27,7 @@ What is compared, and how strictly
        - class argmax: identical for every query, except a query whose two leading REFERENCE logits are closer together
          than ``ARGMAX_MARGIN[layer]`` = the CPU-vs-CPU logit drift measured for that layer (a tie at the resolution of the
          arithmetic: neither implementation's argmax is "the" answer there); any other mismatch fails the test;
-       - boxes: layers 0-2 within 1e-3 for every query; in layers 3, 4, 5 at most ``TAIL_QUERIES`` = 2, 4, 12 of the 900
+       - boxes: layers 0-2 within 1e-3 for every query; in layers 3, 4, 5 at most ``TAIL_QUERIES`` = 2, 3, 11 of the 900
          queries may miss 1e-3, none by more than ``TAIL_TOL`` = 2e-2; p50 <= 1e-4 everywhere.
    * SURVEY 8d's SECOND rig -- weights as torch's constructors draw them, then the reference's own init_weights()
      (zero offset / generator / tau weights, xavier value / output / fusion Linears; fixtures decoder_f8_init.npz,
@@ -37,7 +37,7 @@ What is compared, and how strictly
      configurations (30 queries) and smoke() are literal too.
    Every comparison records what it actually used (differing / imposed camera choices, box misses, argmax mismatches and
    their margins, per layer) in ``USED``; the GPU session writes it to gpurun_out/parity_budget_used.json, and the committed
-   copy is profiles/r03_parity_budget_used.json.
+   copy is profiles/r04_parity_budget_used.json (keyed by session kind: a CPU session writes its own file).
 3. The NMS-free decode is positional and exact (``decode_parity``); the end-to-end detection list is matched one to one
    (``detections_parity``).
 Boxes are compared in the decoder's normalised output space (xyz / pc_range span, log sizes, sin, cos, velocity).
@@ -45,7 +45,9 @@ Boxes are compared in the decoder's normalised output space (xyz / pc_range span
 import numpy as np
 import torch
 
-TAIL_QUERIES = (0, 0, 0, 2, 4, 12)                    # random-everything rig, per layer: queries (of 900) that may miss 1e-3 on the box
+TAIL_QUERIES = (0, 0, 0, 2, 3, 11)                    # random-everything rig, per layer: queries (of 900) that may miss 1e-3 on the box
+                                                      # (round 4: measured maximum over every comparison of the GPU session + 1 -- 1 / 2 / 10,
+                                                      #  profiles/r04_parity_budget_used.json; round 3 allowed 2 / 4 / 12)
 TAIL_BUDGET = tuple(q / 900.0 for q in TAIL_QUERIES)  # ... as a fraction of the queries
 TAIL_TOL = 2e-2                                       # ... and by how much at most (box space; measured maximum 9.9e-3)
 ARGMAX_MARGIN = (4.8e-6, 2.7e-5, 8.8e-5, 2.3e-4, 3.9e-3, 1.2e-2)   # measured CPU-vs-CPU logit drift per layer (see above)

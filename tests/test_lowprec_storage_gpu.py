@@ -13,7 +13,7 @@ BASELINE configs 3 / 5 name bf16.  Round 3 measured bf16 storage only on the ran
      bf16 is not literal on the init rig either (1 / 1 / 3 queries in layers 3-5); **f16 (11 significant bits) IS**: literal on
      both init rigs (max 1.4e-4 / 7.0e-4, argmax identical) and on the random rig's decoder_f8.npz (max 7.5e-4, nothing over
      1e-3) -- but on that rig's chaotic seed (decoder_f8_s1.npz, where fp32 itself has 1 / 8 queries over 1e-3 in layers
-     4 / 5) it has 8 / 33, beyond the tail budget the fp32 path is held to (4 / 12).  f16 value streams would halve the
+     4 / 5) it has 8 / 33, beyond the tail budget the fp32 path is held to (3 / 11).  f16 value streams would halve the
      bytes through the CU's texture path that bound the BEV kernel, so the result is recorded precisely; the
      default keeps fp32 because one committed fixture fails with it.
 (iii) int16 BLOCK storage of the value streams (one power-of-two scale per (pixel, head) block of 64 channels, 14-15 significant

@@ -9,7 +9,8 @@
 //   grad_loc[p] (x,y)  = (W | H) * attn * sum_c grad_out[c] * d bilinear[c] / d(w|h)
 // A 16-lane group owns one (batch, query, head, level, point) sample (dim=64: 4 channels per lane); the
 // channel sums are a butterfly inside the group with one writer per element (deterministic); only the
-// value scatter uses atomics (one contiguous 256-byte head row per group-instruction).
+// value scatter uses atomics.  Round 4: lane c of a group owns channels c + 16 j (not 4c .. 4c+3), so that every atomic
+// instruction adds whole 64-byte segments (see msmv_bwd.hip).
 // The caller zero-fills grad_value; grad_loc / grad_attn are fully overwritten.
 #include "rac_common.h"
 
@@ -46,8 +47,10 @@ __global__ __launch_bounds__(256) void msda_bwd_d64_kernel(const MsdaBwdArgs a)
     const int b = (int)(item / ((long)a.heads * a.Q));
     const float x = a.loc[sc * 2], y = a.loc[sc * 2 + 1];
     const float at = a.attn[sc];
-    const rac_f4 z = {0.f, 0.f, 0.f, 0.f};
-    const rac_f4 g = act ? rac_ld4(a.grad_out + item * 64 + lane16 * 4) : z;
+    float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        g[j] = act ? a.grad_out[item * 64 + 16 * j + lane16] : 0.f;
     const int H = a.H[l], W = a.W[l];
     const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
     const bool in = act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
@@ -55,42 +58,35 @@ __global__ __launch_bounds__(256) void msda_bwd_d64_kernel(const MsdaBwdArgs a)
     const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
     const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
     const int stride = a.heads * 64;
-    const size_t map = (((size_t)b * a.keys + a.start[l]) * a.heads + h) * 64 + lane16 * 4;
+    const size_t map = (((size_t)b * a.keys + a.start[l]) * a.heads + h) * 64 + lane16;
     const float *base = a.value + map;
     float *gbase = a.gvalue + map;
-    const bool ok1 = in && h_low >= 0 && w_low >= 0, ok2 = in && h_low >= 0 && w_high <= W - 1;
-    const bool ok3 = in && h_high <= H - 1 && w_low >= 0, ok4 = in && h_high <= H - 1 && w_high <= W - 1;
-    const size_t o1 = ((size_t)h_low * W + w_low) * stride, o2 = ((size_t)h_low * W + w_high) * stride;
-    const size_t o3 = ((size_t)h_high * W + w_low) * stride, o4 = ((size_t)h_high * W + w_high) * stride;
-    const rac_f4 v1 = ok1 ? rac_ld4(base + o1) : z, v2 = ok2 ? rac_ld4(base + o2) : z;
-    const rac_f4 v3 = ok3 ? rac_ld4(base + o3) : z, v4 = ok4 ? rac_ld4(base + o4) : z;
-    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-    const rac_f4 tg = {g.x * at, g.y * at, g.z * at, g.w * at};
-#define DB_ADD4(ptr, wt)                   \
-    do {                                   \
-        atomicAdd((ptr), (wt) * tg.x);     \
-        atomicAdd((ptr) + 1, (wt) * tg.y); \
-        atomicAdd((ptr) + 2, (wt) * tg.z); \
-        atomicAdd((ptr) + 3, (wt) * tg.w); \
-    } while (0)
-    if (ok1) DB_ADD4(gbase + o1, w1);
-    if (ok2) DB_ADD4(gbase + o2, w2);
-    if (ok3) DB_ADD4(gbase + o3, w3);
-    if (ok4) DB_ADD4(gbase + o4, w4);
-#undef DB_ADD4
-#define DB_DOT(fx)                                                                                   \
-    ((fx(v1.x, v2.x, v3.x, v4.x)) * g.x + (fx(v1.y, v2.y, v3.y, v4.y)) * g.y + (fx(v1.z, v2.z, v3.z, v4.z)) * g.z + \
-     (fx(v1.w, v2.w, v3.w, v4.w)) * g.w)
-#define DB_VAL(a1, a2, a3, a4) (w1 * (a1) + w2 * (a2) + w3 * (a3) + w4 * (a4))
-#define DB_DH(a1, a2, a3, a4) (-hw * (a1) - lw * (a2) + hw * (a3) + lw * (a4))
-#define DB_DW(a1, a2, a3, a4) (-hh * (a1) + hh * (a2) - lh * (a3) + lh * (a4))
-    const float sv = db_group_sum16(DB_DOT(DB_VAL));
-    const float sh = db_group_sum16(DB_DOT(DB_DH));
-    const float sw_ = db_group_sum16(DB_DOT(DB_DW));
-#undef DB_DOT
-#undef DB_VAL
-#undef DB_DH
-#undef DB_DW
+    const bool ok[4] = {in && h_low >= 0 && w_low >= 0, in && h_low >= 0 && w_high <= W - 1,
+                        in && h_high <= H - 1 && w_low >= 0, in && h_high <= H - 1 && w_high <= W - 1};
+    const size_t o[4] = {((size_t)h_low * W + w_low) * stride, ((size_t)h_low * W + w_high) * stride,
+                         ((size_t)h_high * W + w_low) * stride, ((size_t)h_high * W + w_high) * stride};
+    const float tw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+    const float dh[4] = {-hw, -lw, hw, lw}, dw[4] = {-hh, hh, -lh, lh};
+    float sv = 0.f, sh = 0.f, sw_ = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = ok[t] ? base[o[t] + 16 * j] : 0.f;
+        if (ok[t]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                atomicAdd(gbase + o[t] + 16 * j, tw[t] * (g[j] * at));
+        }
+        const float dot = (v[0] * g[0] + v[1] * g[1]) + (v[2] * g[2] + v[3] * g[3]);
+        sv += tw[t] * dot;
+        sh += dh[t] * dot;
+        sw_ += dw[t] * dot;
+    }
+    sv = db_group_sum16(sv);
+    sh = db_group_sum16(sh);
+    sw_ = db_group_sum16(sw_);
     if (act && lane16 == 0) {
         a.gattn[sc] = sv;
         a.gloc[sc * 2] = (float)W * sw_ * at;

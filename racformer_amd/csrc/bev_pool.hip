@@ -24,12 +24,40 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_kernel(int c, int n_interval
     if (grp >= n_intervals)
         return;
     const int start = interval_starts[grp], len = interval_lengths[grp];
+    // Round 4: the interval is walked in chunks of LANES points whose indices and depth values the group's lanes fetch TOGETHER (one
+    // coalesced round trip per chunk instead of two dependent loads per point), and the feature rows of four points are in flight
+    // at once.  An interval is a serial sum (one writer per output element), and the f8 Lift-Splat frustum has intervals of up to
+    // 416 points next to a mean of 26: with index -> depth -> row as a dependent chain per point the longest interval alone took
+    // most of the launch (143 us for 343 MB of L2-resident rows).  Same order of additions as before.
     for (int c0 = ln * 4; c0 < c; c0 += LANES * 4) {
         rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < len; ++i) {
-            const float d = depth[ranks_depth[start + i]];
-            const rac_f4 f = rac_ld4(feat + (size_t)ranks_feat[start + i] * c + c0);
-            acc.x += f.x * d; acc.y += f.y * d; acc.z += f.z * d; acc.w += f.w * d;
+        for (int base = 0; base < len; base += LANES) {
+            const int n = min(LANES, len - base);
+            int my_rf = 0;
+            float my_d = 0.f;
+            if (ln < n) {
+                my_rf = ranks_feat[start + base + ln];
+                my_d = depth[ranks_depth[start + base + ln]];
+            }
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
+                rac_f4 f[4];
+                float d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f[u] = rac_ld4(feat + (size_t)__shfl(my_rf, i + u, LANES) * c + c0);
+                    d[u] = __shfl(my_d, i + u, LANES);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += f[u].x * d[u]; acc.y += f[u].y * d[u]; acc.z += f[u].z * d[u]; acc.w += f[u].w * d[u];
+                }
+            }
+            for (; i < n; ++i) {
+                const rac_f4 f = rac_ld4(feat + (size_t)__shfl(my_rf, i, LANES) * c + c0);
+                const float d = __shfl(my_d, i, LANES);
+                acc.x += f.x * d; acc.y += f.y * d; acc.z += f.z * d; acc.w += f.w * d;
+            }
         }
         *reinterpret_cast<rac_f4 *>(out + (size_t)ranks_bev[start] * c + c0) = acc;
     }
@@ -67,28 +95,69 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_kernel(int c, int n_interval
     const bool live = grp < n_intervals;
     const int start = live ? interval_starts[grp] : 0, len = live ? interval_lengths[grp] : 0;
     const int rf = live ? ranks_feat[start] : 0;
-    // depth gradients: one dot product over channels per point of the interval
-    for (int i = 0; i < len; ++i) {
-        const float *og = out_grad + (size_t)ranks_bev[start + i] * c;
-        float part = 0.f;
-        for (int c0 = ln * 4; c0 < c; c0 += LANES * 4) {
-            const rac_f4 g = rac_ld4(og + c0), f = rac_ld4(feat + (size_t)rf * c + c0);
-            part += (g.x * f.x + g.y * f.y) + (g.z * f.z + g.w * f.w);
+    // depth gradients: one dot product over channels per point of the interval; the points' indices are fetched by the group
+    // together, a chunk of LANES at a time (as in the forward kernel), and two points' rows are in flight at once
+    for (int base = 0; base < len; base += LANES) {
+        const int n = min(LANES, len - base);
+        int my_rb = 0, my_rd = 0;
+        if (ln < n) {
+            my_rb = ranks_bev[start + base + ln];
+            my_rd = ranks_depth[start + base + ln];
         }
+        for (int i = 0; i < n; i += 2) {
+            const bool two = i + 1 < n;
+            const float *og0 = out_grad + (size_t)__shfl(my_rb, i, LANES) * c;
+            const float *og1 = out_grad + (size_t)__shfl(my_rb, two ? i + 1 : i, LANES) * c;
+            float part0 = 0.f, part1 = 0.f;
+            for (int c0 = ln * 4; c0 < c; c0 += LANES * 4) {
+                const rac_f4 f = rac_ld4(feat + (size_t)rf * c + c0), g0 = rac_ld4(og0 + c0), g1 = rac_ld4(og1 + c0);
+                part0 += (g0.x * f.x + g0.y * f.y) + (g0.z * f.z + g0.w * f.w);
+                part1 += (g1.x * f.x + g1.y * f.y) + (g1.z * f.z + g1.w * f.w);
+            }
 #pragma unroll
-        for (int off = LANES / 2; off >= 1; off >>= 1)
-            part += __shfl_xor(part, off, LANES);
-        if (ln == 0)
-            depth_grad[ranks_depth[start + i]] = part;
+            for (int off = LANES / 2; off >= 1; off >>= 1) {
+                part0 += __shfl_xor(part0, off, LANES);
+                part1 += __shfl_xor(part1, off, LANES);
+            }
+            const int rd0 = __shfl(my_rd, i, LANES), rd1 = __shfl(my_rd, two ? i + 1 : i, LANES);
+            if (ln == 0) {
+                depth_grad[rd0] = part0;
+                if (two)
+                    depth_grad[rd1] = part1;
+            }
+        }
     }
     // feature gradients: accumulated over the interval, one writer per element
     if (live)
         for (int c0 = ln * 4; c0 < c; c0 += LANES * 4) {
             rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int i = 0; i < len; ++i) {
-                const float d = depth[ranks_depth[start + i]];
-                const rac_f4 g = rac_ld4(out_grad + (size_t)ranks_bev[start + i] * c + c0);
-                acc.x += g.x * d; acc.y += g.y * d; acc.z += g.z * d; acc.w += g.w * d;
+            for (int base = 0; base < len; base += LANES) {
+                const int n = min(LANES, len - base);
+                int my_rb = 0;
+                float my_d = 0.f;
+                if (ln < n) {
+                    my_rb = ranks_bev[start + base + ln];
+                    my_d = depth[ranks_depth[start + base + ln]];
+                }
+                int i = 0;
+                for (; i + 4 <= n; i += 4) {
+                    rac_f4 g[4];
+                    float d[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        g[u] = rac_ld4(out_grad + (size_t)__shfl(my_rb, i + u, LANES) * c + c0);
+                        d[u] = __shfl(my_d, i + u, LANES);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc.x += g[u].x * d[u]; acc.y += g[u].y * d[u]; acc.z += g[u].z * d[u]; acc.w += g[u].w * d[u];
+                    }
+                }
+                for (; i < n; ++i) {
+                    const rac_f4 g = rac_ld4(out_grad + (size_t)__shfl(my_rb, i, LANES) * c + c0);
+                    const float d = __shfl(my_d, i, LANES);
+                    acc.x += g.x * d; acc.y += g.y * d; acc.z += g.z * d; acc.w += g.w * d;
+                }
             }
             *reinterpret_cast<rac_f4 *>(feat_grad + (size_t)rf * c + c0) = acc;
         }

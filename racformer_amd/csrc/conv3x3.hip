@@ -57,14 +57,14 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ s
     float m = 0.f;
     const long n4 = n >> 2, stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
-        const rac_f4 v0 = rac_ld4(src + i * 4), v1 = rac_ld4(src + (i + stride) * 4);
-        const rac_f4 v2 = rac_ld4(src + (i + 2 * stride) * 4), v3 = rac_ld4(src + (i + 3 * stride) * 4);
-        const float a0 = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
-        const float a1 = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
-        const float a2 = fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w)));
-        const float a3 = fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)));
-        m = fmaxf(m, fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    for (; i + 7 * stride < n4; i += 8 * stride) {   // eight independent 16-byte loads in flight per lane
+        rac_f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = rac_ld4(src + (i + u * stride) * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
     }
     for (; i < n4; i += stride) {
         const rac_f4 v = rac_ld4(src + i * 4);

@@ -270,15 +270,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
                 ah[(m + 1) & 1] = S[row * 8 + (lk ^ f)];
                 al[(m + 1) & 1] = S[row * 8 + ((4 + lk) ^ f)];
             }
+#if defined(RAC_DIAGNOSTIC_BUILD) && defined(CV_ABLATE)
+            // diagnostic builds only (wrong results, timing ablations: DESIGN 3.6): 1 = no LDS writes, 2 = no global loads, 4 = no step barrier
+#define CV_ST(dst_, src_) do { if (!(CV_ABLATE & 1)) dst_ = src_; } while (0)
+#define CV_LD(dst_, expr_) do { if (!(CV_ABLATE & 2)) dst_ = expr_; } while (0)
+#else
+#define CV_ST(dst_, src_) dst_ = src_
+#define CV_LD(dst_, expr_) dst_ = expr_
+#endif
             switch (m) {     // staging piece m: tile ks+1 out of its register into the other LDS stage, tile ks+2 into the register
-            case 0: DA[st0] = ra0; ra0 = a.xs[a_base0 + off_]; break;
-            case 1: DA[st1] = ra1; ra1 = a.xs[a_base1 + off_]; break;
-            case 2: DA[st2] = ra2; ra2 = a.xs[a_base2 + off_]; break;
-            case 3: DA[st3] = ra3; ra3 = a.xs[a_base3 + off_]; break;
-            case 4: DB[st0] = rb0; rb0 = wsrc_[0]; break;
-            case 5: DB[st1] = rb1; rb1 = wsrc_[512]; break;
-            case 6: DB[st2] = rb2; rb2 = wsrc_[1024]; break;
-            default: DB[st3] = rb3; rb3 = wsrc_[1536]; break;
+            case 0: CV_ST(DA[st0], ra0); CV_LD(ra0, a.xs[a_base0 + off_]); break;
+            case 1: CV_ST(DA[st1], ra1); CV_LD(ra1, a.xs[a_base1 + off_]); break;
+            case 2: CV_ST(DA[st2], ra2); CV_LD(ra2, a.xs[a_base2 + off_]); break;
+            case 3: CV_ST(DA[st3], ra3); CV_LD(ra3, a.xs[a_base3 + off_]); break;
+            case 4: CV_ST(DB[st0], rb0); CV_LD(rb0, wsrc_[0]); break;
+            case 5: CV_ST(DB[st1], rb1); CV_LD(rb1, wsrc_[512]); break;
+            case 6: CV_ST(DB[st2], rb2); CV_LD(rb2, wsrc_[1024]); break;
+            default: CV_ST(DB[st3], rb3); CV_LD(rb3, wsrc_[1536]); break;
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -292,7 +300,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[nn], ah[m & 1], acc[m][nn], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if defined(RAC_DIAGNOSTIC_BUILD) && defined(CV_ABLATE) && (CV_ABLATE & 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         __syncthreads();
+#endif
     }
 #else
     for (int ks = 0; ks < KS; ++ks) {

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAC_ABI_VERSION 5
+#define RAC_ABI_VERSION 6
 #define RAC_MAX_LEVELS 8
 #define RAC_MAX_POINTS 128 /* same limit as the reference, msmv_sampling_forward.cu:21 */
 
@@ -303,6 +303,10 @@ int rac_generator_fwd(const void *x_image, const void *w_image, const float *bia
  * Split-precision f16 MFMA (hi / lo per operand, fp32 accumulate), activation scale per pixel.  16-byte aligned pointers. */
 int rac_value_proj_fwd(const float *x, const void *w_image, float w_alpha, const float *add, const float *bias, float *out,
                        int frames, int channels, int HW, int features, void *stream);
+/* rac_value_proj_fwd writing the int16 block storage of rac_quant_i16_fwd (q [frames*HW][256] int16, scale [frames*HW][4] f32):
+ * bit for bit rac_quant_i16_fwd(rac_value_proj_fwd(...)); the LSS BEV value stream of rac_bev_sampling_multi_q16_fwd. */
+int rac_value_proj_q16_fwd(const float *x, const void *w_image, float w_alpha, const float *add, const float *bias, void *q,
+                           float *scale, int frames, int channels, int HW, int features, void *stream);
 
 /* The temporal-fusion convolution of RadarBEVTemporalEncoder (3x3, stride 1, pad 1, Cin -> 256; the 193-GFLOP
  * nn.Conv2d of models/racformer_transformer.py:631,655) as an implicit GEMM on the f16 matrix cores with
@@ -331,6 +335,11 @@ int rac_conv_pack_bias_fwd(const float *src, const float *bias, const float *ama
                            int c_total, int c_offset, int frames_per_group, int live_per_group, void *stream);
 int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
                     float w_alpha, float *out, int N, int H, int W, int Cin, int Cout, void *stream);
+/* rac_conv3x3_fwd whose epilogue writes the int16 block storage of rac_quant_i16_fwd instead of fp32 (the radar BEV value stream,
+ * value_proj composed into the weights: the convolution's result IS the stream rac_bev_sampling_multi_q16_fwd reads):
+ *   q [N*H*W][256] int16, scale [N*H*W][4] f32 -- bit for bit rac_quant_i16_fwd(rac_conv3x3_fwd(...)), without the fp32 stream. */
+int rac_conv3x3_q16_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
+                        float w_alpha, void *q, float *scale, int N, int H, int W, int Cin, int Cout, void *stream);
 
 /* Producer-side pyramid layout: the last stage of the image neck -- the per-level 3x3 / pad 1 /
  * Cin -> 256 output convolution of the FPN (mmdet 2.28.2 FPN.fpn_convs[i], the same structure as the in-tree CustomFPN,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "rac_rowgemm_fwd": (_i, [_vp, _i, _i, _vp]),
     "rac_gemm_split_pack_fwd": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "rac_value_proj_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rac_value_proj_q16_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rac_outproj_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rac_generator_fwd": (_i, [_vp, _vp, _vp, _f, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
     "rac_gru_gate_fwd": (_i, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "rac_conv_pack_fwd": (_i, [_vp, _vp, _vp] + [_i] * 6 + [_vp]),
     "rac_conv_pack_bias_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "rac_conv3x3_fwd": (_i, [_vp] * 5 + [_f, _vp] + [_i] * 5 + [_vp]),
+    "rac_conv3x3_q16_fwd": (_i, [_vp] * 5 + [_f, _vp, _vp] + [_i] * 5 + [_vp]),
     "rac_fpn_conv_fwd": (_i, [_vp] * 4 + [_f, _vp] + [_i] * 5 + [_vp]),
     "rac_conv3x3s2_fwd": (_i, [_vp] * 4 + [_f, _vp] + [_i] * 7 + [_vp]),
     "rac_bev_sampling_fwd": (_i, [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),

@@ -158,15 +158,25 @@ struct ConvArgs {
     int N, H, W, chunks;
     float w_alpha;
     int cams;                 // GROUPED output only: images per (batch, frame)
+    short *q;                 // Q16 output only: [N][H*W][256] int16 mantissas and
+    float *qscale;            //   [N][H*W][4] one power-of-two scale per (pixel, 64-channel block); out is unused
 };
+enum { CV_OUT_NHWC = 0, CV_OUT_GROUPED = 1, CV_OUT_Q16 = 2 };
+__device__ __forceinline__ cv_f4 cv_fma4(cv_f4 a, float s, cv_f4 b)
+{
+    return __builtin_elementwise_fma(a, (cv_f4){s, s, s, s}, b);
+}
 
-// GROUPED = false: out [N][H][W][256] channel-last.  GROUPED = true: the decoder's sampling layout of a feature-pyramid
+// MODE = CV_OUT_NHWC: out [N][H][W][256] channel-last.  CV_OUT_GROUPED: the decoder's sampling layout of a feature-pyramid
 // level, [N / cams * 4][cams][H][W][64] -- image n = (b*T + t) * cams + cam, output channel co = g * 64 + c lands in slot
 // (b*T + t) * 4 + g (models/racformer_transformer.py:112-124: what the reference builds with a reshape / permute copy of
-// the FPN's output; here the FPN's last convolution writes it).
-template <bool GROUPED>
+// the FPN's output; here the FPN's last convolution writes it).  CV_OUT_Q16: the channel-last result in the int16 block
+// storage of quant.hip (the BEV value stream as rac_bev_sampling_multi_q16_fwd reads it), quantised in the epilogue: bit for
+// bit what rac_quant_i16_fwd makes of the CV_OUT_NHWC output, without the 134 MB fp32 stream in between.
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
 {
+    constexpr bool GROUPED = MODE == CV_OUT_GROUPED;
     extern __shared__ uint4 lds4[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wm = wave >> 2, wn = wave & 3;
@@ -360,13 +370,57 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
             for (int m = 0; m < 8; ++m) {
                 const int p = 128 * wm + 16 * m + li;
                 if (p < prows)
-                    *reinterpret_cast<cv_f4 *>(obase + (size_t)p * 64 + c) = acc[m][nn] * unscale + bv;
+                    *reinterpret_cast<cv_f4 *>(obase + (size_t)p * 64 + c) = cv_fma4(acc[m][nn], unscale, bv);
+            }
+        }
+        return;
+    }
+    const float *pbase = a.pixel_bias ? a.pixel_bias + (size_t)tile * CV_TM * CV_COUT : nullptr;
+    if (MODE == CV_OUT_Q16) {
+        // A (pixel, 64-channel block) of the value stream is pixel li of tile m in wave column wn: its 64 values are the 16 this
+        // lane holds (4 tiles nn x 4 registers) and those of the lanes li + 16, li + 32, li + 48 -- block maximum = 16 in-lane
+        // values and two cross-lane steps; every lane then quantises its own 16 values (four 8-byte stores).
+        short *qbase = a.q + ((size_t)n * HW + (size_t)tile * CV_TM) * CV_COUT + 64 * wn + 4 * lk;
+        float *sbase = a.qscale + ((size_t)n * HW + (size_t)tile * CV_TM) * 4 + wn;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            cv_f4 pb[4][4];
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                const int p = min(128 * wm + 16 * (4 * half + mm) + li, prows - 1);
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) {
+                    const int col = 64 * wn + 16 * nn + 4 * lk;
+                    pb[mm][nn] = pbase ? *reinterpret_cast<const cv_f4 *>(pbase + (size_t)p * CV_COUT + col)
+                                       : (a.bias ? *reinterpret_cast<const cv_f4 *>(a.bias + col) : (cv_f4){0.f, 0.f, 0.f, 0.f});
+                }
+            }
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                const int m = 4 * half + mm, p = 128 * wm + 16 * m + li;
+                cv_f4 v[4];
+                float bm = 0.f;
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) {
+                    v[nn] = cv_fma4(acc[m][nn], unscale, pb[mm][nn]);
+                    bm = fmaxf(bm, fmaxf(fmaxf(fabsf(v[nn][0]), fabsf(v[nn][1])), fmaxf(fabsf(v[nn][2]), fabsf(v[nn][3]))));
+                }
+                bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+                bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+                float up, dn;
+                rac_q16_factors(bm, up, dn);
+                if (p < prows) {
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn)
+                        *reinterpret_cast<uint2 *>(qbase + (size_t)p * CV_COUT + 16 * nn) = rac_q16x4(v[nn][0], v[nn][1], v[nn][2], v[nn][3], up);
+                    if (lk == 0)
+                        sbase[(size_t)p * 4] = dn;
+                }
             }
         }
         return;
     }
     float *obase = a.out + ((size_t)n * HW + (size_t)tile * CV_TM) * CV_COUT;
-    const float *pbase = a.pixel_bias ? a.pixel_bias + (size_t)tile * CV_TM * CV_COUT : nullptr;
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
         const int col = 64 * wn + 16 * nn + 4 * lk;
@@ -381,7 +435,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
         for (int m = 0; m < 8; ++m) {
             const int p = 128 * wm + 16 * m + li;
             if (p < prows)
-                *reinterpret_cast<cv_f4 *>(obase + (size_t)p * CV_COUT + col) = acc[m][nn] * unscale + pb[m];
+                *reinterpret_cast<cv_f4 *>(obase + (size_t)p * CV_COUT + col) = cv_fma4(acc[m][nn], unscale, pb[m]);
         }
     }
 }
@@ -570,28 +624,49 @@ extern "C" int rac_conv_pack_bias_fwd(const float *src, const float *bias, const
     return rac_launch_status("rac_conv_pack_bias_fwd");
 }
 
-extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
-                               float w_alpha, float *out, int N, int H, int W, int Cin, int Cout, void *stream)
+static int cv_launch_plain(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax, float w_alpha,
+                           float *out, void *q, float *qscale, int N, int H, int W, int Cin, int Cout, void *stream, const char *what)
 {
-    RAC_CHECK_ARG(Cout == CV_COUT, "rac_conv3x3_fwd: built for %d output channels (got %d)", CV_COUT, Cout);
-    RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "rac_conv3x3_fwd: Cin=%d (multiple of 32)", Cin);
-    RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0, "rac_conv3x3_fwd: N=%d H=%d W=%d", N, H, W);
-    RAC_CHECK_ARG(!pixel_bias || (H * W) % CV_TM == 0, "rac_conv3x3_fwd: a pixel_bias map needs H*W=%d to be a multiple of %d", H * W, CV_TM);
+    RAC_CHECK_ARG(Cout == CV_COUT, "%s: built for %d output channels (got %d)", what, CV_COUT, Cout);
+    RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "%s: Cin=%d (multiple of 32)", what, Cin);
+    RAC_CHECK_ARG(N >= 0 && H > 0 && W > 0, "%s: N=%d H=%d W=%d", what, N, H, W);
+    RAC_CHECK_ARG(!pixel_bias || (H * W) % CV_TM == 0, "%s: a pixel_bias map needs H*W=%d to be a multiple of %d", what, H * W, CV_TM);
     if (N == 0)
         return 0;
-    RAC_CHECK_ARG(xs && ws && amax && out, "rac_conv3x3_fwd: null pointer");
-    RAC_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pixel_bias)) & 15) == 0,
-                  "rac_conv3x3_fwd: out / bias / pixel_bias must be 16-byte aligned");
+    RAC_CHECK_ARG(xs && ws && amax && (out || (q && qscale)), "%s: null pointer", what);
+    RAC_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pixel_bias) |
+                    reinterpret_cast<uintptr_t>(q)) & 15) == 0, "%s: out / bias / pixel_bias must be 16-byte aligned", what);
     ConvArgs a;
     a.xs = reinterpret_cast<const uint4 *>(xs);
     a.ws = reinterpret_cast<const uint4 *>(ws);
     a.bias = bias; a.pixel_bias = pixel_bias; a.amax = amax; a.out = out;
+    a.q = reinterpret_cast<short *>(q); a.qscale = qscale;
     a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = 1;
     const int lds = 2 * CV_STAGE_U4 * 16;
-    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_CONV3X3, reinterpret_cast<const void *>(conv3x3_f16x3_kernel<false>), (int)(lds)))
-        return rc_attr;
-    hipLaunchKernelGGL(conv3x3_f16x3_kernel<false>, dim3((unsigned)(N * ((H * W + CV_TM - 1) / CV_TM))), dim3(512), lds, (hipStream_t)stream, a);
-    return rac_launch_status("rac_conv3x3_fwd");
+    const dim3 grid((unsigned)(N * ((H * W + CV_TM - 1) / CV_TM)));
+    if (q) {
+        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_CONV3X3_Q16, reinterpret_cast<const void *>(conv3x3_f16x3_kernel<CV_OUT_Q16>), lds))
+            return rc_attr;
+        hipLaunchKernelGGL(conv3x3_f16x3_kernel<CV_OUT_Q16>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    } else {
+        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_CONV3X3, reinterpret_cast<const void *>(conv3x3_f16x3_kernel<CV_OUT_NHWC>), lds))
+            return rc_attr;
+        hipLaunchKernelGGL(conv3x3_f16x3_kernel<CV_OUT_NHWC>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    }
+    return rac_launch_status(what);
+}
+
+extern "C" int rac_conv3x3_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
+                               float w_alpha, float *out, int N, int H, int W, int Cin, int Cout, void *stream)
+{
+    return cv_launch_plain(xs, ws, bias, pixel_bias, amax, w_alpha, out, nullptr, nullptr, N, H, W, Cin, Cout, stream, "rac_conv3x3_fwd");
+}
+
+extern "C" int rac_conv3x3_q16_fwd(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax,
+                                   float w_alpha, void *q, float *scale, int N, int H, int W, int Cin, int Cout, void *stream)
+{
+    RAC_CHECK_ARG(N == 0 || (q && scale), "rac_conv3x3_q16_fwd: null pointer");
+    return cv_launch_plain(xs, ws, bias, pixel_bias, amax, w_alpha, nullptr, q, scale, N, H, W, Cin, Cout, stream, "rac_conv3x3_q16_fwd");
 }
 
 extern "C" int rac_fpn_conv_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
@@ -610,11 +685,11 @@ extern "C" int rac_fpn_conv_fwd(const void *xs, const void *ws, const float *bia
     a.xs = reinterpret_cast<const uint4 *>(xs);
     a.ws = reinterpret_cast<const uint4 *>(ws);
     a.bias = bias; a.pixel_bias = nullptr; a.amax = amax; a.out = out;
-    a.N = num_images; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = num_cams;
+    a.N = num_images; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = num_cams; a.q = nullptr; a.qscale = nullptr;
     const int lds = 2 * CV_STAGE_U4 * 16;
-    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_FPN_CONV, reinterpret_cast<const void *>(conv3x3_f16x3_kernel<true>), (int)(lds)))
+    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_FPN_CONV, reinterpret_cast<const void *>(conv3x3_f16x3_kernel<CV_OUT_GROUPED>), (int)(lds)))
         return rc_attr;
-    hipLaunchKernelGGL(conv3x3_f16x3_kernel<true>, dim3((unsigned)(num_images * ((H * W + CV_TM - 1) / CV_TM))), dim3(512), lds,
+    hipLaunchKernelGGL(conv3x3_f16x3_kernel<CV_OUT_GROUPED>, dim3((unsigned)(num_images * ((H * W + CV_TM - 1) / CV_TM))), dim3(512), lds,
                        (hipStream_t)stream, a);
     return rac_launch_status("rac_fpn_conv_fwd");
 }

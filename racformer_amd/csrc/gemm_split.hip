@@ -238,11 +238,15 @@ __global__ __launch_bounds__(768, 1) void gemm_split_kernel(const GemmSplitArgs 
 // = one row).  Per stage and SIMD 192 MFMAs (1.5 us) stand against 32 KB of intake (22 GB/s): matrix-pipe-bound.
 // All eight waves multiply AND load (four pieces each per stage; the two waves of a SIMD alternate between the LDS-DMA
 // issue and their MFMA block); stores, LDS-DMA and loads share vmcnt, so the counted wait covers the stores in between.
-#define GW_ROWS 32                          /* X rows per stage */
-#define GW_STAGE (GW_ROWS * 1024)           /* bytes: K = 256 -> 8 lines = 1 KB per row */
 #define GW_STAGES 4
+#ifndef GW4_LDS_PAD
+#define GW4_LDS_PAD 0                       /* A/B builds: extra LDS bytes requested by the four-wave shape (96 KB in all: one workgroup per CU) */
+#endif
 #ifndef GW_UNROLL
 #define GW_UNROLL 4                         /* stages per trip of the stage loop (a multiple of GW_STAGES) */
+#endif
+#ifndef GW_WIDE_WAVES
+#define GW_WIDE_WAVES 8                     /* waves per workgroup of the wide generator launch: 8 (one workgroup per CU) or 4 (two; A/B builds) */
 #endif
 
 struct GenArgs {
@@ -254,30 +258,44 @@ struct GenArgs {
     int M, N;
     long ld_out;
     int rows_per_wg;   // rows a workgroup walks (blockIdx.y selects the chunk): M for the wide generator, a multiple of
-                       // GW_ROWS for narrow outputs, where the feature blocks alone would leave most CUs idle
+                       // the stage height for narrow outputs, where the feature blocks alone would leave most CUs idle
 };
 
-__global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
+// Two shapes of the same kernel:
+//   <8, 32>  512 threads, one workgroup per CU: 256 features per workgroup, stages of 32 rows (2 x 2 MFMA tiles per wave), 128 KB ring.
+//            Both waves of a SIMD belong to the same workgroup and meet at the same stage barrier: while they store a stage's tile,
+//            wait for the next stage and read its first fragments, the SIMD's matrix pipe has nothing to do (round-4 counters:
+//            50 % MFMA-busy).
+//   <4, 16>  256 threads, TWO workgroups per CU (round 4): 128 features per workgroup, stages of 16 rows (2 x 1 tiles per wave),
+//            64 KB ring each.  The two waves of a SIMD now belong to different workgroups with barriers of their own, so they drift
+//            out of phase and one multiplies while the other is between stages.  Every workgroup still streams the whole X image
+//            (0.9 MB, L2-resident), so the LDS-DMA intake per CU doubles (1.8 MB per launch).
+template <int WAVES, int ROWS>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void generator_ws_kernel(const GenArgs g)
 {
+    constexpr int STAGE = ROWS * 1024;          // bytes: K = 256 -> 8 lines = 1 KB per row
+    constexpr int J = ROWS / 16;                // 16-row MFMA tiles per stage
+    constexpr int PIECES = ROWS / WAVES;        // LDS-DMA pieces (rows) per wave and stage
+    static_assert(PIECES == 4 && (J == 1 || J == 2), "the counted waits below are written for 4 pieces and 2 J stores per stage");
     extern __shared__ char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const int n0 = blockIdx.x * 256 + 32 * wave;          // this wave's 32 features
+    const int n0 = blockIdx.x * (32 * WAVES) + 32 * wave; // this wave's 32 features
     const int m0 = blockIdx.y * g.rows_per_wg;            // this workgroup's rows m0 .. m0 + mrows - 1
     const int mrows = min(g.rows_per_wg, g.M - m0);
-    const int nstages = (mrows + GW_ROWS - 1) / GW_ROWS;
+    const int nstages = (mrows + ROWS - 1) / ROWS;
     const bool full_n = n0 + 32 <= g.N;                   // every feature of this wave is stored (wave-uniform)
 
-    // ---- X loader role: piece = one row (1 KB); wave w moves rows w, w+8, w+16, w+24 of every stage.  LDS slot `lane` of
+    // ---- X loader role: piece = one row (1 KB); wave w moves rows w, w + WAVES, ... of every stage.  LDS slot `lane` of
     // the row receives the row's 16-byte chunk lane ^ (row & 15) (source-side swizzle, see the fragment reads)
     // (ring slots are compile-time constants everywhere: with a run-time slot index hipcc cannot tell an LDS-DMA into one
     //  slot from the fragment reads of another and waits vmcnt(0) before every first read -- the pipeline collapses)
     auto issue = [&](int st, int slot) {
-        char *stage = lds + slot * GW_STAGE;
+        char *stage = lds + slot * STAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = wave + 8 * j;
-            int row = m0 + st * GW_ROWS + r;
+        for (int j = 0; j < PIECES; ++j) {
+            const int r = wave + WAVES * j;
+            int row = m0 + st * ROWS + r;
             row = row < g.M ? row : g.M - 1;           // rows past the end re-read the last row; never stored
             const char *src = g.x + (size_t)row * 1024 + (size_t)((lane ^ (r & 15)) * 16);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -315,9 +333,7 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
     __builtin_amdgcn_s_barrier();
 
     // fragment read: row r = 16j + li of the stage, chunk c = 8 ks + (hi: lk, lo: 4 + lk), LDS slot c ^ (r & 15) = c ^ li
-    // A trip of the outer loop is GW_UNROLL stages with compile-time ring slots.  At the trip's first fragment read hipcc drains
-    // vmcnt(0) (above) -- which also waits for the STORES of the stage before: one exposed store round trip per trip.  With four
-    // stages per trip that was 7 drains per workgroup at 900 rows; with 16 it is two (round 4: ISA + PMC).
+    // A trip of the outer loop is GW_UNROLL stages with compile-time ring slots.
     for (int st0 = 0; st0 < nstages; st0 += GW_UNROLL) {
 #pragma unroll
     for (int u = 0; u < GW_UNROLL; ++u) {
@@ -330,19 +346,19 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
         // nothing (the older ones have landed), with them issued it exposed one full memory latency every four stages
         if (u != 0 && st + 3 < nstages)
             issue(st + 3, (u + 3) & (GW_STAGES - 1));
-        const char *S = lds + (u & (GW_STAGES - 1)) * GW_STAGE;
-        gs_f4 acc[2][2];
+        const char *S = lds + (u & (GW_STAGES - 1)) * STAGE;
+        gs_f4 acc[2][J];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < J; ++j)
                 acc[t][j] = (gs_f4){0.f, 0.f, 0.f, 0.f};
         // X fragments one K step ahead of their MFMAs (two register sets): the LDS latency of step ks + 1 runs under the
-        // twelve MFMAs of step ks instead of in front of them
-        gs_h8 xh[2][2], xl[2][2];
+        // MFMAs of step ks instead of in front of them
+        gs_h8 xh[2][J], xl[2][J];
         auto frag = [&](int ks, int b) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < J; ++j) {
                 const char *rowp = S + (16 * j + li) * 1024;
                 xh[b][j] = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + lk) ^ li) * 16));
                 xl[b][j] = *reinterpret_cast<const gs_h8 *>(rowp + (((8 * ks + 4 + lk) ^ li) * 16));
@@ -353,13 +369,13 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
         for (int ks = 0; ks < 8; ++ks) {
             if (ks + 1 < 8)
                 frag(ks + 1, (ks + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);   // (keeps the four reads above the MFMAs: hipcc otherwise sinks them to their uses)
-            // product-major: four independent accumulators between two MFMAs into the same one (back-to-back dependent MFMAs
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the reads above the MFMAs: hipcc otherwise sinks them to their uses)
+            // product-major: independent accumulators between two MFMAs into the same one (back-to-back dependent MFMAs
             // wait out each other's latency -- the kernel ran at half the MFMA rate)
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < J; ++j) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         if (pr == 0)
@@ -377,8 +393,8 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
             issue(st + 3, 3);
         // C/D layout: col = li (X row), rows 4 lk + r = four consecutive features: one 16-byte store each
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = m0 + st * GW_ROWS + 16 * j + li;
+        for (int j = 0; j < J; ++j) {
+            const int row = m0 + st * ROWS + 16 * j + li;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int n = n0 + 16 * t + 4 * lk;
@@ -395,19 +411,28 @@ __global__ __launch_bounds__(512, 1) void generator_ws_kernel(const GenArgs g)
             }
         }
         // stage st+1 must have landed before anyone reads it.  Issue order of this wave's vector-memory operations:
-        //   ... P(st+1) S(st-2) | P(st+2) S(st-1) | P(st+3) S(st)      (P: 4 pieces, S: up to 4 stores; P before S either way)
-        // A wave whose 32 features and whose stage rows are all inside the output issues exactly 4 stores per stage: at most
-        // 20 younger operations may then remain outstanding behind P(st+1) (fewer pieces follow towards the end).  Any other
-        // wave (features at or beyond N in the last feature block, a partial last row stage: the compiler branches around
-        // stores no lane takes) issues an unknown number of stores: it may only leave the pieces themselves outstanding.
-        const bool four_stores = full_n && (st + 1) * GW_ROWS <= mrows;     // wave-uniform
-        if (four_stores) {
-            if (st + 3 < nstages)
-                asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-            else if (st + 2 < nstages)
-                asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        //   ... P(st+1) S(st-2) | P(st+2) S(st-1) | P(st+3) S(st)      (P: 4 pieces, S: up to 2 J stores; P before S either way)
+        // A wave whose 32 features and whose stage rows are all inside the output issues exactly 2 J stores per stage: at most
+        // 3 * 2J + 2 * 4 younger operations may then remain outstanding behind P(st+1) (fewer pieces follow towards the end).
+        // Any other wave (features at or beyond N in the last feature block, a partial last row stage: the compiler branches
+        // around stores no lane takes) issues an unknown number of stores: it may only leave the pieces themselves outstanding.
+        const bool all_stores = full_n && (st + 1) * ROWS <= mrows;     // wave-uniform
+        if (all_stores) {
+            if (J == 2) {
+                if (st + 3 < nstages)
+                    asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+                else if (st + 2 < nstages)
+                    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+            } else {
+                if (st + 3 < nstages)
+                    asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+                else if (st + 2 < nstages)
+                    asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            }
         } else {
             if (st + 3 < nstages)
                 asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -491,20 +516,29 @@ extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const
         a.x = reinterpret_cast<const char *>(x_image);
         a.w = reinterpret_cast<const char *>(w_image);
         a.bias = bias; a.out = out; a.alpha = alpha; a.M = M; a.N = N; a.ld_out = ld_out;
+        if (GW_WIDE_WAVES == 4 && N >= 128 * 128) {
+            // the wide generator (65536 features): 512 workgroups of four waves, two per CU, every one walks all rows
+            a.rows_per_wg = (M + 15) / 16 * 16;
+            if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_GENERATOR4, reinterpret_cast<const void *>(generator_ws_kernel<4, 16>), GW_STAGES * 16 * 1024 + GW4_LDS_PAD))
+                return rc_attr;
+            hipLaunchKernelGGL((generator_ws_kernel<4, 16>), dim3((N + 127) / 128, 1), dim3(256), GW_STAGES * 16 * 1024 + GW4_LDS_PAD, (hipStream_t)stream, a);
+            return rac_launch_status("rac_generator_fwd");
+        }
         // narrow outputs (the 2189 features of the sampling Linears, not the generator's 65536): cut the rows into chunks so
         // that feature blocks x chunks covers the CUs; every chunk re-reads its 256 weight rows (L2) for at least 32 rows of
         // work.  One workgroup per CU (128 KB of LDS), so at most 256 workgroups: a 257th would wait for a whole round.
         // (Measured at N = 2189, M = 900: 135 workgroups 14.8 us, 261 workgroups 20.5 us; an XCD-major item order that keeps a
         //  feature block's chunks on one L2 changed nothing -- the weights' trip across the fabric is not what bounds it.)
+        constexpr int ROWS = 32;
         const int fblocks = (N + 255) / 256;
         int chunks = fblocks >= 128 ? 1 : 256 / fblocks;
-        const int max_chunks = (M + GW_ROWS - 1) / GW_ROWS;
+        const int max_chunks = (M + ROWS - 1) / ROWS;
         chunks = chunks > max_chunks ? max_chunks : chunks;
-        a.rows_per_wg = ((M + chunks - 1) / chunks + GW_ROWS - 1) / GW_ROWS * GW_ROWS;
+        a.rows_per_wg = ((M + chunks - 1) / chunks + ROWS - 1) / ROWS * ROWS;
         chunks = (M + a.rows_per_wg - 1) / a.rows_per_wg;
-        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_GENERATOR, reinterpret_cast<const void *>(generator_ws_kernel), (int)(GW_STAGES * GW_STAGE)))
-        return rc_attr;
-        hipLaunchKernelGGL(generator_ws_kernel, dim3(fblocks, chunks), dim3(512), GW_STAGES * GW_STAGE, (hipStream_t)stream, a);
+        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_GENERATOR, reinterpret_cast<const void *>(generator_ws_kernel<8, 32>), GW_STAGES * ROWS * 1024))
+            return rc_attr;
+        hipLaunchKernelGGL((generator_ws_kernel<8, 32>), dim3(fblocks, chunks), dim3(512), GW_STAGES * ROWS * 1024, (hipStream_t)stream, a);
         return rac_launch_status("rac_generator_fwd");
     }
     GemmSplitArgs g;

@@ -22,18 +22,9 @@ __global__ __launch_bounds__(256) void quant_i16_block64_kernel(const float *__r
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1)
             m = fmaxf(m, __shfl_xor(m, off, 64));
-        // exponent arithmetic only: eb = biased exponent of the block maximum, clamped so that both powers of two below are
-        // normal floats (an all-zero / denormal block gets q = 0 with the smallest scale; inf / nan saturate)
-        int eb = (int)((__float_as_uint(m) >> 23) & 255u);
-        eb = eb < 15 ? 15 : (eb > 254 ? 254 : eb);
-        const float up = __uint_as_float((unsigned)(268 - eb) << 23);      // 2^(14 - (eb - 127)): |x| * up < 2^15
-        const float dn = __uint_as_float((unsigned)(eb - 14) << 23);       // 2^((eb - 127) - 14)
-        const float lim = 32767.f;
-        const int q0 = (int)fminf(fmaxf(rintf(x.x * up), -lim), lim), q1 = (int)fminf(fmaxf(rintf(x.y * up), -lim), lim);
-        const int q2 = (int)fminf(fmaxf(rintf(x.z * up), -lim), lim), q3 = (int)fminf(fmaxf(rintf(x.w * up), -lim), lim);
-        uint2 o;
-        o.x = ((unsigned)q0 & 0xffffu) | ((unsigned)q1 << 16);
-        o.y = ((unsigned)q2 & 0xffffu) | ((unsigned)q3 << 16);
+        float up, dn;
+        rac_q16_factors(m, up, dn);
+        const uint2 o = rac_q16x4(x.x, x.y, x.z, x.w, up);
         *reinterpret_cast<uint2 *>(q + b * 64 + lane16 * 4) = o;
         if (lane16 == 0)
             scale[b] = dn;

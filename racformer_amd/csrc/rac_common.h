@@ -13,7 +13,7 @@ void rac_set_error(const char *fmt, ...);
 // limit) on the CURRENT device unless an earlier call already did, from any thread; 0 or the HIP error (rac_last_error set).  (capi.cpp)
 int rac_set_dynamic_lds_once(int id, const void *func, int bytes);
 enum { RAC_ATTR_GEMM_SPLIT = 0, RAC_ATTR_GENERATOR, RAC_ATTR_CONV3X3, RAC_ATTR_CONV3X3S2, RAC_ATTR_MIXING_F32, RAC_ATTR_MIXING_F16,
-       RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV };
+       RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV, RAC_ATTR_GENERATOR4, RAC_ATTR_CONV3X3_Q16, RAC_ATTR_VALUE_PROJ_Q16 };
 
 #define RAC_CHECK_ARG(cond, ...)            \
     do {                                    \
@@ -122,4 +122,27 @@ __device__ __forceinline__ void rac_split_f16(float v, _Float16 &hi, _Float16 &l
 {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
+}
+
+// int16 block storage of a BEV value stream (quant.hip; the q16 epilogues of conv3x3.hip and value_proj.hip): value = q * dn with
+// dn = 2^(e - 14), e = floor(log2(max |block|)).  Exponent arithmetic only: eb = biased exponent of the block maximum, clamped so that
+// both powers of two are normal floats (an all-zero / denormal block gets q = 0 with the smallest scale; inf / nan saturate).
+__device__ __forceinline__ void rac_q16_factors(float block_max, float &up, float &dn)
+{
+    int eb = (int)((__float_as_uint(block_max) >> 23) & 255u);
+    eb = eb < 15 ? 15 : (eb > 254 ? 254 : eb);
+    up = __uint_as_float((unsigned)(268 - eb) << 23);      // 2^(14 - (eb - 127)): |x| * up < 2^15
+    dn = __uint_as_float((unsigned)(eb - 14) << 23);       // 2^((eb - 127) - 14)
+}
+__device__ __forceinline__ int rac_q16(float x, float up)
+{
+    return (int)fminf(fmaxf(rintf(x * up), -32767.f), 32767.f);
+}
+// four values -> four int16 (8 bytes)
+__device__ __forceinline__ uint2 rac_q16x4(float x, float y, float z, float w, float up)
+{
+    uint2 o;
+    o.x = ((unsigned)rac_q16(x, up) & 0xffffu) | ((unsigned)rac_q16(y, up) << 16);
+    o.y = ((unsigned)rac_q16(z, up) & 0xffffu) | ((unsigned)rac_q16(w, up) << 16);
+    return o;
 }

@@ -27,6 +27,7 @@ typedef float vp_f4 __attribute__((ext_vector_type(4)));
 #define VP_ROWS 32
 #define VP_BUF (VP_ROWS * 1024 + VP_ROWS * 4)   /* X image of a stage + its per-row output scales */
 #define VP_LDS (2 * VP_BUF + 8 * VP_ROWS * 4)   /* two buffers + the waves' partial maxima */
+#define VP_LDS_Q16 (VP_LDS + 8 * VP_ROWS * 4)   /* + the waves' partial block maxima of the q16 epilogue */
 
 struct ValueProjArgs {
     const float *x;      // [F][256][HW]
@@ -34,12 +35,18 @@ struct ValueProjArgs {
     const float *add;    // [HW][256] or null
     const float *bias;   // [256] or null (used when add is null)
     float *out;          // [F*HW][256]
+    short *q;            // QOUT: [F*HW][256] int16 mantissas and
+    float *qscale;       //   [F*HW][4] one power-of-two scale per (pixel, 64-feature block) -- quant.hip's storage; out unused
     float w_alpha;       // 2^-s of the weight image
     int HW;
     long M;              // F * HW
     int pixels_per_wg;   // multiple of VP_ROWS
 };
 
+// QOUT: the result leaves in the int16 block storage of quant.hip (what rac_bev_sampling_multi_q16_fwd reads), bit for bit what
+// rac_quant_i16_fwd makes of the fp32 output: a (pixel, head) block of 64 features is held by two waves (32 features each), so
+// the block maximum is 8 in-lane values, two cross-lane steps and one exchange between the partner waves through LDS.
+template <bool QOUT>
 __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs g)
 {
     extern __shared__ char lds[];
@@ -177,6 +184,41 @@ __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs 
             }
         }
         // ---- epilogue: C/D layout col = li (pixel), rows 4 lk + r = four consecutive features: one 16-byte store
+        if (QOUT) {
+            float *pmax = reinterpret_cast<float *>(lds + VP_LDS);          // [8 waves][32 pixels]
+            vp_f4 v[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a = salpha[16 * j + li];
+                float bm = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    v[j][t] = __builtin_elementwise_fma(acc[t][j], (vp_f4){a, a, a, a}, addv[j][t]);
+                    bm = fmaxf(bm, fmaxf(fmaxf(fabsf(v[j][t][0]), fabsf(v[j][t][1])), fmaxf(fabsf(v[j][t][2]), fabsf(v[j][t][3]))));
+                }
+                bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+                bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+                if (lk == 0)
+                    pmax[wave * VP_ROWS + 16 * j + li] = bm;
+            }
+            __syncthreads();                              // (C) the partner wave's half-block maxima are visible
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = 16 * j + li;
+                const float bm = fmaxf(pmax[wave * VP_ROWS + r], pmax[(wave ^ 1) * VP_ROWS + r]);
+                float up, dn;
+                rac_q16_factors(bm, up, dn);
+                if (gp + r < mend) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        *reinterpret_cast<uint2 *>(g.q + (size_t)(gp + r) * 256 + 32 * wave + 16 * t + 4 * lk) =
+                            rac_q16x4(v[j][t][0], v[j][t][1], v[j][t][2], v[j][t][3], up);
+                    if (lk == 0 && (wave & 1) == 0)
+                        g.qscale[(size_t)(gp + r) * 4 + (wave >> 1)] = dn;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = 16 * j + li;
@@ -185,34 +227,54 @@ __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs 
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int n = 32 * wave + 16 * t + 4 * lk;
-                    *reinterpret_cast<vp_f4 *>(g.out + (size_t)(gp + r) * 256 + n) = acc[t][j] * a + addv[j][t];
+                    *reinterpret_cast<vp_f4 *>(g.out + (size_t)(gp + r) * 256 + n) = __builtin_elementwise_fma(acc[t][j], (vp_f4){a, a, a, a}, addv[j][t]);
                 }
             }
         }
     }
 }
 
-extern "C" int rac_value_proj_fwd(const float *x, const void *w_image, float w_alpha, const float *add, const float *bias, float *out,
-                                  int frames, int channels, int HW, int features, void *stream)
+static int vp_launch(const float *x, const void *w_image, float w_alpha, const float *add, const float *bias, float *out, void *q,
+                     float *qscale, int frames, int channels, int HW, int features, void *stream, const char *what)
 {
-    RAC_CHECK_ARG(channels == 256 && features == 256, "rac_value_proj_fwd: built for 256 -> 256 (got %d -> %d)", channels, features);
-    RAC_CHECK_ARG(frames >= 0 && HW >= VP_ROWS && HW % VP_ROWS == 0, "rac_value_proj_fwd: frames=%d H*W=%d (H*W must be a multiple of %d)",
+    RAC_CHECK_ARG(channels == 256 && features == 256, "%s: built for 256 -> 256 (got %d -> %d)", what, channels, features);
+    RAC_CHECK_ARG(frames >= 0 && HW >= VP_ROWS && HW % VP_ROWS == 0, "%s: frames=%d H*W=%d (H*W must be a multiple of %d)", what,
                   frames, HW, VP_ROWS);
     if (frames == 0)
         return 0;
-    RAC_CHECK_ARG(x && w_image && out, "rac_value_proj_fwd: null pointer");
+    RAC_CHECK_ARG(x && w_image && (out || (q && qscale)), "%s: null pointer", what);
     RAC_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(add) |
-                    reinterpret_cast<uintptr_t>(bias)) & 15) == 0, "rac_value_proj_fwd: pointers must be 16-byte aligned");
+                    reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(q)) & 15) == 0, "%s: pointers must be 16-byte aligned", what);
     ValueProjArgs a;
     a.x = x; a.w = reinterpret_cast<const char *>(w_image); a.add = add; a.bias = bias; a.out = out; a.w_alpha = w_alpha;
+    a.q = reinterpret_cast<short *>(q); a.qscale = qscale;
     a.HW = HW; a.M = (long)frames * HW;
     // one workgroup per CU (its weights fill the register file): cut the pixels into about 256 chunks of whole stages
     long ppw = (a.M + 255) / 256;
     ppw = (ppw + VP_ROWS - 1) / VP_ROWS * VP_ROWS;
     a.pixels_per_wg = (int)ppw;
     const unsigned grid = (unsigned)((a.M + ppw - 1) / ppw);
-    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_VALUE_PROJ, reinterpret_cast<const void *>(value_proj_kernel), (int)(VP_LDS)))
-        return rc_attr;
-    hipLaunchKernelGGL(value_proj_kernel, dim3(grid), dim3(512), VP_LDS, (hipStream_t)stream, a);
-    return rac_launch_status("rac_value_proj_fwd");
+    if (q) {
+        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_VALUE_PROJ_Q16, reinterpret_cast<const void *>(value_proj_kernel<true>), (int)(VP_LDS_Q16)))
+            return rc_attr;
+        hipLaunchKernelGGL(value_proj_kernel<true>, dim3(grid), dim3(512), VP_LDS_Q16, (hipStream_t)stream, a);
+    } else {
+        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_VALUE_PROJ, reinterpret_cast<const void *>(value_proj_kernel<false>), (int)(VP_LDS)))
+            return rc_attr;
+        hipLaunchKernelGGL(value_proj_kernel<false>, dim3(grid), dim3(512), VP_LDS, (hipStream_t)stream, a);
+    }
+    return rac_launch_status(what);
+}
+
+extern "C" int rac_value_proj_fwd(const float *x, const void *w_image, float w_alpha, const float *add, const float *bias, float *out,
+                                  int frames, int channels, int HW, int features, void *stream)
+{
+    return vp_launch(x, w_image, w_alpha, add, bias, out, nullptr, nullptr, frames, channels, HW, features, stream, "rac_value_proj_fwd");
+}
+
+extern "C" int rac_value_proj_q16_fwd(const float *x, const void *w_image, float w_alpha, const float *add, const float *bias, void *q,
+                                      float *scale, int frames, int channels, int HW, int features, void *stream)
+{
+    RAC_CHECK_ARG(frames == 0 || (q && scale), "rac_value_proj_q16_fwd: null pointer");
+    return vp_launch(x, w_image, w_alpha, add, bias, nullptr, q, scale, frames, channels, HW, features, stream, "rac_value_proj_q16_fwd");
 }

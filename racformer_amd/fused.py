@@ -504,22 +504,32 @@ class ConvImage:
                    "rac_conv_pack_bias_fwd")
         return self
 
-    def conv(self, ws, w_alpha, bias=None, pixel_bias=None):
+    def conv(self, ws, w_alpha, bias=None, pixel_bias=None, q16=False):
+        """-> [N,H,W,256] fp32 channel-last, or with ``q16`` the same result in the int16 block storage of quantize_values_i16
+        (q int16 [N, H*W, 4, 64], scale f32 [N, H*W, 4]), quantised in the kernel's epilogue (rac_conv3x3_q16_fwd)."""
         N, H, W = self.N, self.H, self.W
-        out = torch.empty(N, H, W, 256, device=self.dev, dtype=torch.float32)
         if pixel_bias is not None and (tuple(pixel_bias.shape) != (H * W, 256) or not pixel_bias.is_contiguous()
                                        or pixel_bias.dtype != torch.float32 or not pixel_bias.is_cuda):
             raise RuntimeError("ConvImage.conv: pixel_bias must be a contiguous float32 CUDA [H*W, 256] tensor")
+        if q16:
+            out = torch.empty(N, H * W, 4, 64, device=self.dev, dtype=torch.int16)
+            scale = torch.empty(N, H * W, 4, device=self.dev, dtype=torch.float32)
+        else:
+            out = torch.empty(N, H, W, 256, device=self.dev, dtype=torch.float32)
         ev = _lib.timer.record("temporal_fusion_conv") if _lib.timer is not None else None
         if ev:
             ev[0].record()
-        _lib.check(_lib.lib().rac_conv3x3_fwd(_lib.ptr(self.xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None,
-                                              _lib.ptr(pixel_bias) if pixel_bias is not None else None, _lib.ptr(self.amax),
-                                              float(w_alpha), _lib.ptr(out), N, H, W, self.cin, 256, _lib.stream_ptr()),
-                   "rac_conv3x3_fwd")
+        head = (_lib.ptr(self.xs), _lib.ptr(ws), _lib.ptr(bias) if bias is not None else None,
+                _lib.ptr(pixel_bias) if pixel_bias is not None else None, _lib.ptr(self.amax), float(w_alpha))
+        tail = (N, H, W, self.cin, 256, _lib.stream_ptr())
+        if q16:
+            rc, what = _lib.lib().rac_conv3x3_q16_fwd(*head, _lib.ptr(out), _lib.ptr(scale), *tail), "rac_conv3x3_q16_fwd"
+        else:
+            rc, what = _lib.lib().rac_conv3x3_fwd(*head, _lib.ptr(out), *tail), "rac_conv3x3_fwd"
         if ev:
             ev[1].record()
-        return out
+        _lib.check(rc, what)
+        return (out, scale) if q16 else out
 
     def conv_s2(self, ws, w_alpha, bias, cin, out=None):
         """3x3 / stride 2 / pad 1 convolution of the image's first ``cin`` channels -> [N, 64, H/2, W/2] fp32 (NCHW), or
@@ -691,25 +701,36 @@ def pack_gemm_split_weight(weight):
     return img, 2.0 ** (-s) / SPLIT_ACT_SCALE
 
 
-def value_proj_fused(maps, w_image, w_alpha, add=None, bias=None):
+def value_proj_fused(maps, w_image, w_alpha, add=None, bias=None, q16=False):
     """maps f32 [F, 256, H, W] (channel-first BEV maps), w_image f16 [256, 8, 64] (pack_gemm_split_weight), w_alpha = 2^-s of the
-    image, add f32 [H*W, 256] (frame-independent term) or bias [256] -> f32 [F, H*W, 256] = maps^T @ W^T + add (rac_value_proj_fwd)."""
+    image, add f32 [H*W, 256] (frame-independent term) or bias [256] -> f32 [F, H*W, 256] = maps^T @ W^T + add (rac_value_proj_fwd);
+    with ``q16`` the same result in the int16 block storage of quantize_values_i16: (q int16 [F, H*W, 4, 64], scale f32 [F, H*W, 4]),
+    quantised in the kernel's epilogue (rac_value_proj_q16_fwd)."""
     _lib.require_gpu(maps, w_image, what="value_proj_fused")
     F_, C, H, W = maps.shape
     if maps.dtype != torch.float32 or not maps.is_contiguous() or w_image.dtype != torch.float16 or tuple(w_image.shape) != (256, 8, 64):
         raise RuntimeError("value_proj_fused: maps must be contiguous float32 [F,256,H,W], w_image f16 [256,8,64]")
     if add is not None and (add.dtype != torch.float32 or not add.is_contiguous() or tuple(add.shape) != (H * W, 256)):
         raise RuntimeError("value_proj_fused: add must be a contiguous float32 [H*W, 256] tensor")
-    out = torch.empty(F_, H * W, 256, device=maps.device, dtype=torch.float32)
+    if q16:
+        out = torch.empty(F_, H * W, 4, 64, device=maps.device, dtype=torch.int16)
+        scale = torch.empty(F_, H * W, 4, device=maps.device, dtype=torch.float32)
+    else:
+        out = torch.empty(F_, H * W, 256, device=maps.device, dtype=torch.float32)
     ev = _lib.timer.record("value_proj_fwd") if _lib.timer is not None else None
     if ev:
         ev[0].record()
-    rc = _lib.lib().rac_value_proj_fwd(_lib.ptr(maps), _lib.ptr(w_image), float(w_alpha), _lib.ptr(add) if add is not None else None,
-                                       _lib.ptr(bias) if bias is not None else None, _lib.ptr(out), F_, C, H * W, 256, _lib.stream_ptr())
+    head = (_lib.ptr(maps), _lib.ptr(w_image), float(w_alpha), _lib.ptr(add) if add is not None else None,
+            _lib.ptr(bias) if bias is not None else None)
+    tail = (F_, C, H * W, 256, _lib.stream_ptr())
+    if q16:
+        rc, what = _lib.lib().rac_value_proj_q16_fwd(*head, _lib.ptr(out), _lib.ptr(scale), *tail), "rac_value_proj_q16_fwd"
+    else:
+        rc, what = _lib.lib().rac_value_proj_fwd(*head, _lib.ptr(out), *tail), "rac_value_proj_fwd"
     if ev:
         ev[1].record()
-    _lib.check(rc, "rac_value_proj_fwd")
-    return out
+    _lib.check(rc, what)
+    return (out, scale) if q16 else out
 
 
 def generator_fused(x_image, w_image, bias, alpha, timer_name="mixing_generator_gemm", ld_out=None):

@@ -40,6 +40,7 @@ def run(cfg, g, inputs, init_rig, pyramid_dtype=torch.float32, round_levels=(), 
         syn.fill_params(tr, int(g["weight_seed"]))
     tr = tr.to(DEV)
     layer = tr.decoder.decoder_layer
+    layer.value_storage = "f32"       # (the formats measured here are emulated on the fp32 streams)
     layer.sampling.force_views = [torch.as_tensor(np.asarray(v)).to(DEV).contiguous() for v in g["views"]]
     tr.decoder.feature_dtype = pyramid_dtype
     qb, qf, pyr, lss, radar = inputs

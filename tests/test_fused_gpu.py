@@ -607,6 +607,64 @@ def test_value_proj_kernel_vs_float64(F_, H, W):
     assert ((got_b.double() - (want - add.double() + lin.bias.double())).abs() / scale).max().item() < 4 * e_fp32 + 1e-6
 
 
+@pytest.mark.parametrize("N,H,W,pixel_bias", [(8, 128, 128, True), (3, 16, 16, False), (2, 32, 64, True)])
+def test_conv3x3_q16_epilogue_is_the_quantiser_of_the_fp32_output(N, H, W, pixel_bias):
+    """rac_conv3x3_q16_fwd (the temporal-fusion convolution writing the int16 block storage of the radar value stream in its
+    epilogue) against rac_quant_i16_fwd applied to rac_conv3x3_fwd's fp32 output on the same image: mantissas and scales bit for
+    bit, incl. blocks spanning many octaves (per-pixel bias map of mixed magnitude) and an all-zero block."""
+    from racformer_amd.fused import ConvImage, pack_conv3x3_weight, quantize_values_i16
+    g = torch.Generator().manual_seed(N * H + W)
+    conv = torch.nn.Conv2d(96, 256, 3, padding=1)
+    with torch.no_grad():
+        conv.weight[64:128] *= 1e-4                # a head (64 output channels) of tiny values next to ordinary ones
+        conv.weight[128:192] = 0.0                 # and one that is exactly the bias
+        conv.bias[128:192] = 0.0
+    x = (torch.randn(N, 96, H, W, generator=g) * torch.exp(torch.randn(N, 1, H, W, generator=g) * 2.0)).to(DEV)
+    ws, alpha = pack_conv3x3_weight(conv.weight.to(DEV))
+    pb = None
+    if pixel_bias:
+        pb = torch.randn(H * W, 256, generator=g) * torch.exp(torch.randn(H * W, 1, generator=g) * 3.0)
+        pb[:, 128:192] = 0.0
+        pb = pb.to(DEV).contiguous()
+    bias = None if pixel_bias else conv.bias.detach().to(DEV)
+    img = ConvImage(N, H, W, 96, x.device).begin([x]).pack(x, 0)
+    f32 = img.conv(ws, alpha, bias, pb)
+    q, sc = img.conv(ws, alpha, bias, pb, q16=True)
+    wq, wsc = quantize_values_i16(f32.view(N, H * W, 4, 64))
+    torch.cuda.synchronize()
+    assert tuple(q.shape) == (N, H * W, 4, 64) and q.dtype == torch.int16 and tuple(sc.shape) == (N, H * W, 4)
+    assert torch.equal(sc, wsc) and torch.equal(q, wq)
+    assert int(q[:, :, 2].abs().max()) == 0 and int(q[:, :, 0].abs().max()) >= 16384      # the zero head; full-range mantissas elsewhere
+
+
+@pytest.mark.parametrize("F_,H,W", [(8, 128, 128), (3, 16, 16), (1, 8, 4)])
+def test_value_proj_q16_epilogue_is_the_quantiser_of_the_fp32_output(F_, H, W):
+    """rac_value_proj_q16_fwd against rac_quant_i16_fwd(rac_value_proj_fwd(.)): bit for bit (the block maximum of a head is
+    combined across the two waves that hold its 64 features)."""
+    from racformer_amd.fused import SPLIT_ACT_SCALE, pack_gemm_split_weight, quantize_values_i16, value_proj_fused
+    g = torch.Generator().manual_seed(F_ * H + W + 1)
+    w = torch.randn(256, 256, generator=g) * 0.06
+    w[64:128] *= 1e-5
+    w[192:256] = 0.0
+    x = torch.randn(F_, 256, H, W, generator=g) * torch.exp(torch.randn(F_, 1, H, W, generator=g) * 3.0)
+    x[0, :, 0, 0] = 0.0
+    add = torch.randn(H * W, 256, generator=g)
+    add[:, 192:256] = 0.0
+    add[0] = 0.0
+    x, add = x.to(DEV), add.to(DEV).contiguous()
+    w_img, alpha = pack_gemm_split_weight(w.to(DEV))
+    f32 = value_proj_fused(x, w_img, alpha * SPLIT_ACT_SCALE, add=add)
+    q, sc = value_proj_fused(x, w_img, alpha * SPLIT_ACT_SCALE, add=add, q16=True)
+    wq, wsc = quantize_values_i16(f32.view(F_, H * W, 4, 64))
+    torch.cuda.synchronize()
+    assert torch.equal(sc, wsc) and torch.equal(q, wq)
+    assert int(q[:, :, 3].abs().max()) == 0 and int(q[0, 0].abs().max()) == 0           # the zero head, the all-zero pixel
+    b = torch.randn(256, generator=g).to(DEV)
+    q2, sc2 = value_proj_fused(x, w_img, alpha * SPLIT_ACT_SCALE, bias=b, q16=True)
+    wq2, wsc2 = quantize_values_i16(value_proj_fused(x, w_img, alpha * SPLIT_ACT_SCALE, bias=b).view(F_, H * W, 4, 64))
+    assert torch.equal(sc2, wsc2) and torch.equal(q2, wq2)
+
+
 def test_head_finish_kernel_matches_torch():
     """rac_head_finish_fwd against the reference's own element-wise tail (nan_to_num of both stacked outputs,
     racformer_transformer.py:58; centre scaling + column order, racformer_head.py:124-131), incl. NaN and +-inf entries:

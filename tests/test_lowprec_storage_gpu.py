@@ -112,3 +112,45 @@ def test_decoder_int16_block_value_streams_random_rig_same_budget(golden_dir, na
     (cls, box, _), _ = run_with_reference_views(lambda force: run_decoder_gpu(cfg, seed, wseed, force, value_storage="i16"), g["views"],
                                                 name + " (i16 values)")
     decoder_parity(cls, box, g["cls"], g["box"], what=name + " (i16 values)")
+
+
+def test_decoder_int16_value_streams_producer_epilogues_equal_the_quantiser_launches():
+    """`value_storage = "i16"` takes the two streams from their producers' own epilogues (rac_conv3x3_q16_fwd, rac_value_proj_q16_fwd);
+    with `fused_q16_producers = False` the fp32 streams are written and quantised by rac_quant_i16_fwd launches.  Same bits out of
+    six free-running layers (the epilogues ARE that quantiser applied to the same fp32 values)."""
+    cfg, seed, wseed = syn.F8, 23, 24
+    a = run_decoder_gpu(cfg, seed, wseed, value_storage="i16")
+    b = run_decoder_gpu(cfg, seed, wseed, value_storage="i16", fused_q16_producers=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+def test_head_small6_int16_value_streams_measured_gap(golden_dir):
+    """Why int16 block storage of the value streams is opt-in and not the product default: on the reduced 30-query head fixture
+    (random-everything rig, criterion LITERAL: no tail) the fp32 streams keep every query of every layer within 1e-3 (measured
+    2.4e-4 ... 5.5e-4 at most in the last layer, depending on whether the reference's camera choices are imposed), the int16 streams
+    leave the last layer at 8.6e-4 ... 1.1e-3 -- the free-running form of this comparison (test_head_forward_and_detections_vs_reference
+    run with int16 streams) FAILS the literal criterion on one query -- and at five times the fp32 path's median error (2.7e-5
+    against 5.3e-6).  Recorded as measured, with bounds on both sides."""
+    from parity import head_boxes_normalised
+    from test_parity_gpu import DEV, build_head
+    cfg, name = syn.SMALL6, "head_small6.npz"
+    g = np.load(os.path.join(golden_dir, name))
+    seed, wseed = int(g["seed"]), int(g["weight_seed"])
+    ref_n = head_boxes_normalised(g["all_bbox_preds"], cfg.pc_range)
+    errs = {}
+    for storage in ("f32", "i16"):
+        head = build_head(cfg, g, seed, wseed)
+        layer = head.transformer.decoder.decoder_layer
+        layer.value_storage = storage
+        layer.sampling.force_views = [torch.as_tensor(np.asarray(v)).to(DEV).contiguous() for v in g["views"]]
+        with torch.no_grad():
+            preds = head([f.to(DEV) for f in syn.make_pyramid(cfg, seed)], syn.make_bev(cfg, seed, 0).to(DEV),
+                         syn.make_bev(cfg, seed, 1).to(DEV), syn.make_img_metas(cfg))
+        torch.cuda.synchronize()
+        eb = (head_boxes_normalised(preds["all_bbox_preds"].cpu(), cfg.pc_range) - torch.as_tensor(ref_n)).abs().amax(-1).flatten(1)
+        errs[storage] = ([float(x) for x in eb.max(1).values], [float(x) for x in eb.median(1).values])
+        assert (preds["all_cls_scores"].cpu().argmax(-1) == torch.as_tensor(g["all_cls_scores"]).argmax(-1)).all()
+    print("head_small6 box error per layer (max, median):", errs)
+    assert max(errs["f32"][0]) < 1e-3
+    assert max(errs["i16"][0][:5]) < 1e-3 and errs["i16"][0][5] < 3e-3
+    assert errs["i16"][1][5] > errs["f32"][1][5], "int16 value streams now as accurate as fp32 on this fixture: reconsider the default (DESIGN 3.11)"

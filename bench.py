@@ -443,7 +443,7 @@ def main():
     # no event brackets, so the timed region is K replays and the dominant kernel is bracketed in K eager steps of the same
     # work right behind it (same kernels, same inputs, same stream).
     if captured is None:
-        _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "msmv_fwd"))
+        _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "mixing_sampled_fwd", "msmv_fwd"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -470,7 +470,7 @@ def main():
             dt1 = time.perf_counter() - t1
             single = {"value": args.steps / dt1, "unit": "samples/s", "ms_per_step": 1e3 * dt1 / args.steps,
                       "note": "one captured plan in flight (each sample's kernels run alone): per-sample latency"}
-        _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "msmv_fwd"))
+        _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "mixing_sampled_fwd", "msmv_fwd"))
         for _ in range(args.steps):
             eager_step()
         fence()
@@ -497,7 +497,10 @@ def main():
         elapsed = max(float(t.item()) for t in allr)      # max over ranks
         merged = dp.merge_interleaved(out, world)           # one sample per rank per step, dataset order
         assert tuple(merged.shape) == (world, 300, 11)
-    msmv_ms = timer.mean_ms("sampling4d_fwd") or timer.mean_ms("msmv_fwd")
+    # the dominant kernel: since round 4 the adaptive sampling runs INSIDE the mixing kernel (rac_mixing_sampled_fwd); with
+    # decoder_layer.fuse_sampling_mixing = False it is the stand-alone sampling kernel of rounds 1-4
+    fused_sm = bool(timer.mean_ms("mixing_sampled_fwd"))
+    msmv_ms = timer.mean_ms("mixing_sampled_fwd") or timer.mean_ms("sampling4d_fwd") or timer.mean_ms("msmv_fwd")
     bev_streams = 2 if aux.mean_ms("bev_sampling_x2_fwd") else 1        # radar + LSS in one launch
     msda_ms = aux.mean_ms("bev_sampling_x2_fwd") or aux.mean_ms("bev_sampling_fwd") or aux.mean_ms("msda_fwd")
 
@@ -512,15 +515,22 @@ def main():
     S = cfg.batch * cfg.num_frames * cfg.num_groups
     P = cfg.num_points * cfg.img_depth_num
     out_elems = S * cfg.num_query * cfg.channels * P
-    per_launch = [msmv_algorithmic_bytes(loc, shapes, elt, out_elems) for loc, shapes in cap.captured]
+    # fused kernel: the gather's bytes as SURVEY 8(d) counts them, WITHOUT the sampled-feature tensor (it is never written), plus what the
+    # mixing half moves: the item's generated parameters (fp32) in, the out_proj operand image (f16 hi + lo = 4 bytes per value) out
+    Pin_ = cfg.num_points * cfg.num_frames * cfg.img_depth_num
+    mix_bytes = cfg.batch * cfg.num_query * cfg.num_groups * ((cfg.channels * cfg.channels + 128 * Pin_) * 4 + 128 * cfg.channels * 4)
+    per_launch = [msmv_algorithmic_bytes(loc, shapes, elt, 0 if fused_sm else out_elems) for loc, shapes in cap.captured]
+    if fused_sm:
+        per_launch = [(b_ + mix_bytes, f_) for b_, f_ in per_launch]
     b_alg = float(np.mean([b for b, _ in per_launch]))
     in_frac = [float(np.mean(f)) for _, f in per_launch]
     full_shapes = cap.captured[0][1]
     n_pts = S * cfg.num_query * P
     b_alg_closed = sum(min(n_pts * 4 * c * elt, s_ * n_ * h * w * c * elt) for (s_, n_, h, w, c) in full_shapes) \
-        + n_pts * 3 * 4 + n_pts * cfg.num_levels * 4 + out_elems * 4
+        + n_pts * 3 * 4 + n_pts * cfg.num_levels * 4 + (mix_bytes if fused_sm else out_elems * 4)
     achieved = b_alg / (msmv_ms * 1e-3) / 1e9 if msmv_ms else None
-    traffic, traffic_src = pmc_traffic("sampling4d_c64_kernel", "racformer_amd/csrc/sampling_fused.hip", args.config)
+    traffic, traffic_src = pmc_traffic("mixing_c64_f16x3_kernel<4>", "racformer_amd/csrc/mixing.hip", args.config) if fused_sm else \
+        pmc_traffic("sampling4d_c64_kernel", "racformer_amd/csrc/sampling_fused.hip", args.config)
     bev_traffic, _ = pmc_traffic("bev_sampling", "racformer_amd/csrc/bev_fused.hip", args.config)
     # MSDA algorithmic bytes of SURVEY 8(d) for one BEV launch (value stream read once + loc + weights + output)
     bev_h, bev_w = cfg.bev_hw
@@ -585,7 +595,9 @@ def main():
                    "sample_seeds_this_rank": [seed + i for i in range(len(lanes) or 1)] if not args.same_inputs_per_lane else [seed],
                    "parallelism": f"dp{world}", "bev_value_stream_storage": "int16-block" if args.value_storage == "i16" else "f32",
                    "pyramid_layout": "pregrouped [B*T*G,N,H,W,C]" if args.pregrouped else "reference [B,T*N,G*C,H,W] (regroup timed)"},
-        "roofline": {"bound": "hbm", "kernel": "sampling4d_c64_kernel (rac_sampling4d_fwd: keypoints + projection + view select + gather)",
+        "roofline": {"bound": "hbm", "kernel": "mixing_c64_f16x3_kernel<4> (rac_mixing_sampled_fwd: keypoints + projection + view select + gather "
+                               "of the item's 96 points AND both adaptive mixings + LayerNorms, one launch per layer)" if fused_sm else
+                               "sampling4d_c64_kernel (rac_sampling4d_fwd: keypoints + projection + view select + gather)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "traffic_note": traffic_src,
@@ -593,7 +605,9 @@ def main():
                      # the Infinity Cache absorb re-sampled pixels: the kernel is limited by its tap requests through L1/L2
                      # (gather request rate), not by HBM bandwidth.
                      "hbm_frac_measured": (traffic / (msmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and msmv_ms else None,
-                     "limiter": "L1/L2 gather-request rate (HBM-side traffic is below the algorithmic bytes)",
+                     "limiter": "the CU's texture path (1.41 GB of tap requests through L1 / L2) beside the 0.35 GB parameter / output stream of the "
+                                "mixing half" if fused_sm else "L1/L2 gather-request rate (HBM-side traffic is below the algorithmic bytes)",
+                     "sampling_inside_mixing_kernel": fused_sm,
                      "avg_launch_ms": msmv_ms, "launches_per_step": len(cap.captured),
                      "timed_in": "HIP events on the launch stream inside the timed region" if captured is None else
                                  f"HIP events on the launch stream over {args.steps} eager steps of the same work right behind the "

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAC_ABI_VERSION 6
+#define RAC_ABI_VERSION 7
 #define RAC_MAX_LEVELS 8
 #define RAC_MAX_POINTS 128 /* same limit as the reference, msmv_sampling_forward.cu:21 */
 
@@ -268,6 +268,22 @@ enum {
 int rac_mixing_fwd(const float *x, const float *params, float param_scale, float *out, void *out_split,
                    float split_scale, int ld_params, int num_query, int groups, int in_points, int channels, int out_points,
                    float eps, int mfma_mode, void *stream);
+
+/* rac_sampling4d_fwd and rac_mixing_fwd (RAC_MIX_F16X3) as ONE kernel: the mixing workgroup of a (query, group) item gathers the
+ * item's T * NP * D sampling points itself -- keypoints, projection, first-valid-view selection, level softmax and bilinear taps
+ * computed by the code of the stand-alone sampling kernel, so the sampled features are bit for bit what rac_sampling4d_fwd writes
+ * -- while the item's generated parameters are on their way from HBM; the [B,Q,G,T*P,64] tensor between
+ * RaCFormerSampling (models/racformer_transformer.py:361-408, sparsebev_sampling.py:45-131) and AdaptiveMixing (:589-603) never
+ * exists.  Arguments: those of rac_sampling4d_fwd without `out` / `compact`, then those of rac_mixing_fwd without `x` / `mfma_mode`
+ * (num_query = B * Q, in_points = T * NP * D <= 96).  Built for 4 fp32 levels of 64 channels per group; every level's T * G slots
+ * of one sample must stay below 2 GiB.  Other shapes: the two stand-alone entry points. */
+int rac_mixing_sampled_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox, const float *box_table,
+                           const float *offsets, const float *ray_logits, const float *scale_logits, const float *time_diff,
+                           const float *lidar2img, float *loc_out, float *w_out, const unsigned char *view_in, int ld_off,
+                           int ld_ray, int ld_scale, int B, int T, int N, int G, int Q, int NP, int D, int C,
+                           const float *pc_range, const float *depth_base, float d_region, float image_h, float image_w,
+                           float eps_proj, int dtype, const float *params, float param_scale, float *out, void *out_split,
+                           float split_scale, int ld_params, int out_points, float eps_ln, void *stream);
 
 /* Split-precision GEMM operand image: nn.Linear weight [N][K] f32 -> f16 [N][K/32][hi 32 | lo 32] of weight * scale
  * (per 32 values of K one 128-byte line; hi + lo carry 22 significant bits).  Packed once per set of weights. */

@@ -37,6 +37,8 @@ SIGNATURES = {
     "rac_refine_fwd": (_i, [_vp] * 5 + [_i] * 3 + [_f, _vp]),
     "rac_head_finish_fwd": (_i, [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _i, _vp, _vp]),
     "rac_mixing_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _f] + [_i] * 6 + [_f, _i, _vp]),
+    "rac_mixing_sampled_fwd": (_i, [_vp, _vp, _i] + [_vp] * 10 + [_i] * 3 + [_i] * 8 + [_vp, _vp] + [_f] * 4 + [_i]
+                               + [_vp, _f, _vp, _vp, _f, _i, _i, _f, _vp]),
     "rac_sasa_fwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp, _vp]),
     "rac_decode_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _i, _vp]),
     "rac_rowgemm_fwd": (_i, [_vp, _i, _i, _vp]),

@@ -81,7 +81,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ s
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+        // non-negative floats order like their bit patterns.  The word only ever grows, so a block whose maximum does not exceed
+        // what it reads there has nothing to add: after the first few blocks almost none issues the atomic (2048 atomics on one
+        // address serialise in L2)
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED))
+            atomicMax(out, bits);
     }
 }
 

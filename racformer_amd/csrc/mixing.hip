@@ -16,6 +16,8 @@
 // free (x: 68 floats, M / Y: 80, S: P_pad+4); S is staged in two 64-row halves so that two
 // workgroups fit in a CU's 160 KB LDS and one's staging overlaps the other's MFMAs.
 #include "rac_common.h"
+#include "s4d_device.h"
+#include <string.h>
 
 typedef float mix_f4 __attribute__((ext_vector_type(4)));
 
@@ -36,6 +38,13 @@ struct MixArgs {
     int nq, G, P, ld_params;
     float eps, split_scale;
     float param_scale;    // every generated parameter is multiplied by this on load (the split GEMM's power-of-two alpha)
+};
+
+// rac_mixing_sampled_fwd: the mixing kernel gathers its own x -- the adaptive 4D sampling of the item's T * P points (s4d_device.h)
+// runs inside the workgroup while the item's 64 KB of generated parameters are on their way from HBM
+struct MixSampArgs {
+    MixArgs m;      // (x unused when s.feat[0] != nullptr)
+    S4dArgs s;      // as for rac_sampling4d_fwd; out unused; P = points per frame, m.P = T * P
 };
 
 __device__ __forceinline__ float mix_wave_sum(float v)
@@ -328,8 +337,20 @@ __device__ __forceinline__ void mix_split4(const rac_f4 v, float scale, rac_h4 &
     rac_split_f16(v.w * scale, hi.w, lo.w);
 }
 
-__global__ __launch_bounds__(256, 3) void mixing_c64_f16x3_kernel(const MixArgs a)
+#ifndef MSG_LB
+#define MSG_LB 2   /* levels per load batch of the in-kernel gather (8 taps in flight per lane): the register budget of three workgroups per CU */
+#endif
+// LS = 0: x [items, P, 64] is read from memory (rac_mixing_fwd).  LS = L > 0: x is gathered here from the L-level feature pyramid
+// (rac_mixing_sampled_fwd): after issuing the loads of its parameters the workgroup computes the item's T * P keypoints and tap
+// tables (one thread each, s4d_keypoint / s4d_taps_of_level: the code of the stand-alone sampling kernel), gathers them with the
+// lane mapping the x staging below already has (a 16-lane group per point, 4 channels per lane, 6 points per group) -- the same
+// taps, weights and FMA order as sampling4d_c64_kernel, so x is bit-identical to what that kernel would have written -- and
+// converts the sums straight into the bf16 operand images.  The 88 MB x tensor of a layer never exists, and the gather (bound
+// by the CU's texture path) runs under the parameter stream (bound by HBM) of the other workgroups of the CU.
+template <int LS>
+__global__ __launch_bounds__(256, 3) void mixing_c64_f16x3_kernel(const MixSampArgs A)
 {
+    const MixArgs &a = A.m;
     extern __shared__ float smem[];
     unsigned char *lds = reinterpret_cast<unsigned char *>(smem);
     __bf16 *sX1 = reinterpret_cast<__bf16 *>(lds);                         // [96][80] x 3 terms
@@ -381,12 +402,14 @@ __global__ __launch_bounds__(256, 3) void mixing_c64_f16x3_kernel(const MixArgs 
     };
     rac_f4 vx[6], vs0[6], vs1[6];
     float mv[2][8];
+    if (LS == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
-        vx[k] = (rac_f4){0.f, 0.f, 0.f, 0.f};
-        if (r < P)
-            vx[k] = rac_ld4(gx + r * MIX_C + c4 * 4);
+        for (int k = 0; k < 6; ++k) {
+            const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
+            vx[k] = (rac_f4){0.f, 0.f, 0.f, 0.f};
+            if (r < P)
+                vx[k] = rac_ld4(gx + r * MIX_C + c4 * 4);
+        }
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -396,9 +419,102 @@ __global__ __launch_bounds__(256, 3) void mixing_c64_f16x3_kernel(const MixArgs 
 #pragma unroll
     for (int k = 0; k < 6; ++k)
         vs0[k] = load_S(0, k);
+    if (LS == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
-        vs1[k] = load_S(1, k);
+        for (int k = 0; k < 6; ++k)
+            vs1[k] = load_S(1, k);
+    }
+    if (LS > 0) {
+        // ---- x gathered in place (the parameter loads above are in flight meanwhile) ---------------------------------------
+        constexpr int L = LS > 0 ? LS : 1;
+        const S4dArgs &sa = A.s;
+        const int Ppt = sa.P, T = sa.T, N = sa.N;
+        const int b = q / sa.Q, qq = q - b * sa.Q;
+        // LDS for this phase, over the region the x images take afterwards: tap table [L][96][4 offsets | 4 weights], the
+        // lidar2img matrices of the T frames, one flag per point (some tap inside a map)
+        float *stab = smem;
+        constexpr int lstride = MIX_PMAX * 8;
+        float *sl2i = stab + L * lstride;                                           // [T*N][16]
+        unsigned char *sval = reinterpret_cast<unsigned char *>(sl2i + T * N * 16); // [96]
+        for (int i = tid; i < T * N * 16; i += 256)
+            sl2i[i] = sa.l2i[(size_t)b * T * N * 16 + i];
+        __syncthreads();
+        for (int i = tid; i < P; i += 256) {
+            const int t = i / Ppt, p = i - t * Ppt;
+            float loc3[3], wl[L];
+            s4d_keypoint<L>(sa, sl2i + t * N * 16, b, t, g, qq, p, loc3, wl);
+            const float lu = loc3[0], lv = loc3[1];
+            const int view = (int)loc3[2] & 255;
+            const unsigned slot_in_b = (unsigned)(t * sa.G + g);                   // the item's slot of frame t inside batch element b
+            bool any = false;
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                any = s4d_taps_of_level<float>(sa.H[l], sa.W[l], lu, lv, view, wl[l], slot_in_b * sa.feat_bytes[l], stab + l * lstride + i * 8) || any;
+            sval[i] = any ? 1 : 0;
+            if (sa.loc_out) {
+                const size_t sl = ((size_t)b * T + t) * sa.G + g;
+                float *lo = sa.loc_out + ((sl * sa.Q + qq) * Ppt + p) * 3;
+                lo[0] = lu;
+                lo[1] = lv;
+                lo[2] = (float)((int)loc3[2] >> 8) / (float)max(N - 1, 1);
+                float *wo = sa.w_out + ((sl * sa.Q + qq) * Ppt + p) * L;
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    wo[l] = wl[l];
+            }
+        }
+        __syncthreads();
+        // one descriptor per level over the T * G slots of batch element b (tap offsets carry the slot; the host checked that
+        // they stay below S4D_TAP_OUTSIDE); b through readfirstlane: a scalar descriptor, no waterfall loop around the loads
+        const int b_uni = __builtin_amdgcn_readfirstlane(b);
+        __amdgpu_buffer_rsrc_t rsrc[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const unsigned bytes_b = (unsigned)(T * sa.G) * sa.feat_bytes[l];
+            rsrc[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(sa.feat[l]) + (size_t)b_uni * bytes_b), 0,
+                                                        bytes_b, 0x00020000);
+        }
+        const unsigned lane_off = (unsigned)((tid & 15) * 16);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int r = (tid >> 4) + 16 * k;            // the row (point) this 16-lane group stages as vx[k]
+            rac_acc4 acc4 = rac_acc4_zero();
+            if (r < P && sval[r]) {
+                const float *e = stab + r * 8;
+#pragma unroll
+                for (int l0 = 0; l0 < L; l0 += MSG_LB) {
+                    rac_f4 v[MSG_LB][4], tw[MSG_LB];
+#pragma unroll
+                    for (int u = 0; u < MSG_LB; ++u) {
+                        const int l = l0 + u;
+                        if (l < L) {
+                            const s4d_u4 o = *reinterpret_cast<const s4d_u4 *>(e + l * lstride);
+                            tw[u] = *reinterpret_cast<const rac_f4 *>(e + l * lstride + 4);
+                            v[u][0] = s4d_tap<float>(rsrc[l], o.x + lane_off);
+                            v[u][1] = s4d_tap<float>(rsrc[l], o.y + lane_off);
+                            v[u][2] = s4d_tap<float>(rsrc[l], o.z + lane_off);
+                            v[u][3] = s4d_tap<float>(rsrc[l], o.w + lane_off);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < MSG_LB; ++u) {
+                        if (l0 + u < L) {
+                            const float w4[4] = {tw[u].x, tw[u].y, tw[u].z, tw[u].w};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                rac_tap_fma(acc4, v[u][c].x, v[u][c].y, v[u][c].z, v[u][c].w, w4[c]);
+                        }
+                    }
+                }
+            }
+            rac_acc4_get(acc4, vx[k].x, vx[k].y, vx[k].z, vx[k].w);
+        }
+        __syncthreads();      // every wave is past its last tap-table read: the region takes the x images now
+        // (the second half of S is requested only now: its 24 registers were the gather's; it lands under step 1)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            vs1[k] = load_S(1, k);
+    }
 
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -557,11 +673,78 @@ extern "C" int rac_mixing_fwd(const float *x, const float *params, float param_s
         static_assert(3 * MIXH_LDS_BYTES <= 160 * 1024, "three workgroups per CU");
         static_assert(MIXH_REGION_BYTES >= MIX_OUT * MIX_C * 4, "output tile must fit the shared region");
         static_assert(MIXH_SS >= MIX_PMAX + 8 && (MIXH_SS * 2) % 16 == 0, "S row stride");
-        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_MIXING_F16, reinterpret_cast<const void *>(mixing_c64_f16x3_kernel), (int)((int)MIXH_LDS_BYTES)))
-        return rc_attr;
-        hipLaunchKernelGGL(mixing_c64_f16x3_kernel, dim3(num_query * groups), dim3(256), MIXH_LDS_BYTES, (hipStream_t)stream, a);
+        if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_MIXING_F16, reinterpret_cast<const void *>(mixing_c64_f16x3_kernel<0>), (int)((int)MIXH_LDS_BYTES)))
+            return rc_attr;
+        MixSampArgs A;
+        memset(&A.s, 0, sizeof(A.s));
+        A.m = a;
+        hipLaunchKernelGGL(mixing_c64_f16x3_kernel<0>, dim3(num_query * groups), dim3(256), MIXH_LDS_BYTES, (hipStream_t)stream, A);
         return rac_launch_status("rac_mixing_fwd");
     }
     hipLaunchKernelGGL(mixing_c64_kernel, dim3(num_query * groups), dim3(256), lds, (hipStream_t)stream, a);
     return rac_launch_status("rac_mixing_fwd");
+}
+
+// AdaptiveMixing core with the adaptive 4D sampling inside (models/racformer_transformer.py:361-408 + sparsebev_sampling.py:45-131 +
+// msmv_sampling_forward.cu:75-164 feeding :589-603): arguments = those of rac_sampling4d_fwd (without `out`: the sampled features
+// stay on chip) followed by those of rac_mixing_fwd (without `x`).  Built for what the decoder runs: fp32 pyramid of 4 levels,
+// 64 channels per group, T * NP * D <= 96 points per item, split-precision MFMA mode.
+extern "C" int rac_mixing_sampled_fwd(const void *const *feats, const int32_t *hw, int L, const float *query_bbox, const float *box_table,
+                                      const float *offsets, const float *ray_logits, const float *scale_logits, const float *time_diff,
+                                      const float *lidar2img, float *loc_out, float *w_out, const unsigned char *view_in, int ld_off,
+                                      int ld_ray, int ld_scale, int B, int T, int N, int G, int Q, int NP, int D, int C,
+                                      const float *pc_range, const float *depth_base, float d_region, float image_h, float image_w,
+                                      float eps_proj, int dtype, const float *params, float param_scale, float *out, void *out_split,
+                                      float split_scale, int ld_params, int out_points, float eps_ln, void *stream)
+{
+    RAC_CHECK_ARG(L == 4, "rac_mixing_sampled_fwd: L=%d (built for 4 levels)", L);
+    RAC_CHECK_ARG(C == MIX_C && out_points == MIX_OUT, "rac_mixing_sampled_fwd: built for 64 channels per group and 128 out points (got %d, %d)", C, out_points);
+    RAC_CHECK_ARG(dtype == RAC_F32, "rac_mixing_sampled_fwd: fp32 feature maps only (dtype %d)", dtype);
+    RAC_CHECK_ARG(B >= 0 && Q >= 0 && T >= 1 && N >= 1 && N <= S4D_MAX_CAMS && G >= 1 && NP >= 1 && D >= 1 && D <= S4D_MAX_DEPTH,
+                  "rac_mixing_sampled_fwd: bad sizes B=%d T=%d N=%d G=%d Q=%d NP=%d D=%d", B, T, N, G, Q, NP, D);
+    const int Ppt = NP * D, P = T * Ppt;
+    RAC_CHECK_ARG(P <= MIX_PMAX, "rac_mixing_sampled_fwd: T * NP * D = %d points per item (at most %d)", P, MIX_PMAX);
+    RAC_CHECK_ARG(ld_params >= G * (MIX_C * MIX_C + MIX_OUT * P) && ld_params % 4 == 0 && (MIX_C * MIX_C + MIX_OUT * P) % 4 == 0,
+                  "rac_mixing_sampled_fwd: parameter row stride %d", ld_params);
+    RAC_CHECK_ARG(ld_off >= G * Ppt * 3 && ld_ray >= D && ld_scale >= G * T * Ppt * L, "rac_mixing_sampled_fwd: row strides too small");
+    RAC_CHECK_ARG((loc_out == nullptr) == (w_out == nullptr), "rac_mixing_sampled_fwd: loc_out and w_out go together");
+    if (B == 0 || Q == 0)
+        return 0;
+    RAC_CHECK_ARG(feats && hw && query_bbox && box_table && offsets && ray_logits && scale_logits && time_diff && lidar2img && pc_range &&
+                      depth_base && params && (out || out_split), "rac_mixing_sampled_fwd: null pointer");
+    RAC_CHECK_ARG((size_t)L * MIX_PMAX * 32 + (size_t)T * N * 64 + MIX_PMAX <= (size_t)MIXH_REGION_BYTES,
+                  "rac_mixing_sampled_fwd: T * N = %d camera matrices do not fit beside the tap table", T * N);
+    MixSampArgs A;
+    memset(&A, 0, sizeof(A));
+    S4dArgs &s = A.s;
+    for (int l = 0; l < RAC_MAX_LEVELS; ++l) {
+        s.H[l] = s.W[l] = 1;
+    }
+    for (int l = 0; l < L; ++l) {
+        RAC_CHECK_ARG(feats[l] != nullptr && hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "rac_mixing_sampled_fwd: level %d", l);
+        s.feat[l] = feats[l];
+        s.H[l] = hw[2 * l];
+        s.W[l] = hw[2 * l + 1];
+        const size_t bytes = (size_t)N * s.H[l] * s.W[l] * 64 * 4;      // one slot's maps
+        RAC_CHECK_ARG(bytes * T * G < (size_t)S4D_TAP_OUTSIDE,
+                      "rac_mixing_sampled_fwd: the T * G slots of level %d hold %zu bytes per sample (the tap offsets are 31-bit)", l, bytes * T * G);
+        s.feat_bytes[l] = (unsigned)bytes;
+    }
+    s.qbox = query_bbox; s.box = box_table; s.off = offsets; s.ray = ray_logits; s.scale = scale_logits;
+    s.time_diff = time_diff; s.l2i = lidar2img; s.out = nullptr; s.loc_out = loc_out; s.w_out = w_out; s.view_in = view_in;
+    for (int i = 0; i < S4D_MAX_DEPTH; ++i)
+        s.depth_base[i] = i < D ? depth_base[i] : 0.f;
+    for (int i = 0; i < 6; ++i)
+        s.pc[i] = pc_range[i];
+    s.d_region = d_region; s.image_h = image_h; s.image_w = image_w; s.eps = eps_proj;
+    s.L = L; s.B = B; s.T = T; s.N = N; s.G = G; s.Q = Q; s.NP = NP; s.D = D; s.P = Ppt;
+    s.ld_off = ld_off; s.ld_ray = ld_ray; s.ld_scale = ld_scale;
+    MixArgs &a = A.m;
+    a.x = nullptr; a.params = params; a.out = out;
+    a.out_split = reinterpret_cast<_Float16 *>(out_split); a.split_scale = split_scale; a.param_scale = param_scale;
+    a.nq = B * Q; a.G = G; a.P = P; a.ld_params = ld_params; a.eps = eps_ln;
+    if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_MIXING_SAMPLED, reinterpret_cast<const void *>(mixing_c64_f16x3_kernel<4>), (int)MIXH_LDS_BYTES))
+        return rc_attr;
+    hipLaunchKernelGGL(mixing_c64_f16x3_kernel<4>, dim3(B * Q * G), dim3(256), MIXH_LDS_BYTES, (hipStream_t)stream, A);
+    return rac_launch_status("rac_mixing_sampled_fwd");
 }

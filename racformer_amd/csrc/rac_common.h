@@ -13,7 +13,7 @@ void rac_set_error(const char *fmt, ...);
 // limit) on the CURRENT device unless an earlier call already did, from any thread; 0 or the HIP error (rac_last_error set).  (capi.cpp)
 int rac_set_dynamic_lds_once(int id, const void *func, int bytes);
 enum { RAC_ATTR_GEMM_SPLIT = 0, RAC_ATTR_GENERATOR, RAC_ATTR_CONV3X3, RAC_ATTR_CONV3X3S2, RAC_ATTR_MIXING_F32, RAC_ATTR_MIXING_F16,
-       RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV, RAC_ATTR_GENERATOR4, RAC_ATTR_CONV3X3_Q16, RAC_ATTR_VALUE_PROJ_Q16 };
+       RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV, RAC_ATTR_GENERATOR4, RAC_ATTR_CONV3X3_Q16, RAC_ATTR_VALUE_PROJ_Q16, RAC_ATTR_MIXING_SAMPLED };
 
 #define RAC_CHECK_ARG(cond, ...)            \
     do {                                    \

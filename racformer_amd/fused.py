@@ -262,6 +262,79 @@ def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5, split
     return out
 
 
+def mixing_sampled_fused(mlvl_feats, query_bbox, offsets, ray_logits, scale_logits, time_diff, lidar2img, num_frames, num_groups,
+                         num_points, depth_num, pc_range, d_region, image_h, image_w, params, out_points=128, eps_proj=1e-5, eps=1e-5,
+                         debug=False, box_table=None, view_in=None, param_scale=1.0):
+    """sampling4d_fused + mixing_fused(split=True, f16x3=True) as ONE launch (rac_mixing_sampled_fwd): the mixing workgroup of an
+    item gathers its own sampled features (bit for bit what sampling4d_fused returns) while its parameters stream in; the
+    [B,Q,G,T*P,C] tensor never exists.  -> the f16 line image [B*Q, G*256, 64] for outproj_fused (with debug=True also the kernel's
+    locations [S,Q,P,3] and level weights [S,Q,P,L]).  Same hooks as sampling4d_fused (view_in, the timer's capture_inputs)."""
+    feats = list(mlvl_feats)
+    L = len(feats)
+    _lib.require_gpu(*feats, query_bbox, time_diff, lidar2img, params, what="mixing_sampled_fused")
+    B, Q, _ = query_bbox.shape
+    T, G, NP, D = num_frames, num_groups, num_points, depth_num
+    P = NP * D
+    S, N, _, _, C = feats[0].shape
+    if S != B * T * G or lidar2img.shape[1] != T * N:
+        raise RuntimeError("mixing_sampled_fused: feature slots / lidar2img do not match B*T*G / T*N")
+    if not mixing_sampled_supported(feats, T, P):
+        raise RuntimeError("mixing_sampled_fused: built for 4 contiguous fp32 levels of 64 channels and T*P <= 96 points per item")
+    p_off, ld_off = _rows(offsets, G * P * 3, "mixing_sampled_fused(offsets)")
+    p_ray, ld_ray = _rows(ray_logits, D, "mixing_sampled_fused(ray_logits)")
+    p_sc, ld_sc = _rows(scale_logits, G * T * P * L, "mixing_sampled_fused(scale_logits)")
+    p_par, ld_par = _rows(params, G * (C * C + out_points * T * P), "mixing_sampled_fused(params)")
+    if box_table is None:
+        box_table = box_prep(query_bbox, pc_range)
+    out = torch.empty(B * Q, G * out_points * C // 32, 64, device=query_bbox.device, dtype=torch.float16)
+    loc_out = w_out = None
+    capture = _lib.timer is not None and getattr(_lib.timer, "capture_inputs", False)
+    want_debug, debug = debug, debug or capture
+    if debug:
+        loc_out = torch.empty(S, Q, P, 3, device=out.device, dtype=torch.float32)
+        w_out = torch.empty(S, Q, P, L, device=out.device, dtype=torch.float32)
+    if view_in is not None:
+        if view_in.dtype != torch.uint8 or tuple(view_in.shape) != (S, Q, P) or not view_in.is_cuda or not view_in.is_contiguous():
+            raise RuntimeError(f"mixing_sampled_fused: view_in must be a contiguous CUDA uint8 [{S},{Q},{P}] tensor")
+        key = (view_in.data_ptr(), view_in._version, N)
+        if key not in _checked_views:        # (a host read: once per tensor, so that a captured plan's forwards issue none)
+            if int(view_in.max()) >= N:
+                raise RuntimeError("mixing_sampled_fused: view_in holds a camera index >= N")
+            if len(_checked_views) > 256:
+                _checked_views.clear()
+            _checked_views.add(key)
+    ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    hw = (ctypes.c_int32 * (2 * L))(*[int(x) for f in feats for x in f.shape[2:4]])
+    pc = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    ev = _lib.timer.record("mixing_sampled_fwd") if _lib.timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = _lib.lib().rac_mixing_sampled_fwd(
+        ptrs, hw, L, _lib.ptr(query_bbox), _lib.ptr(box_table), p_off, p_ray, p_sc, _lib.ptr(time_diff), _lib.ptr(lidar2img),
+        _lib.ptr(loc_out) if debug else None, _lib.ptr(w_out) if debug else None, _lib.ptr(view_in) if view_in is not None else None,
+        ld_off, ld_ray, ld_sc, B, T, N, G, Q, NP, D, C, pc, _depth_base(float(d_region), D), float(d_region), float(image_h),
+        float(image_w), float(eps_proj), _lib.dtype_code(feats[0]), p_par, float(param_scale), None, _lib.ptr(out), SPLIT_ACT_SCALE,
+        ld_par, out_points, float(eps), _lib.stream_ptr())
+    if ev:
+        ev[1].record()
+    _lib.check(rc, "rac_mixing_sampled_fwd")
+    if capture:  # bench.py: the locations this launch sampled at, for the algorithmic-byte count
+        _lib.timer.captured.append((loc_out, [tuple(f.shape) for f in feats]))
+    return (out, loc_out, w_out) if want_debug else out
+
+
+def mixing_sampled_supported(feats, num_frames, points_per_frame):
+    """Shapes rac_mixing_sampled_fwd is built for: 4 contiguous fp32 CUDA levels [S,N,H,W,64], at most 96 points per item, and every
+    level's slots of one sample below 2 GiB."""
+    feats = list(feats)
+    if len(feats) != 4 or num_frames * points_per_frame > 96:
+        return False
+    for f in feats:
+        if not (f.is_cuda and f.dtype == torch.float32 and f.dim() == 5 and f.shape[-1] == 64 and f.is_contiguous()):
+            return False
+    return True
+
+
 def refine_fused(proposal, delta, time_diff_safe, num_ray):
     """refine_bbox + velocity / time_diff + theta_d2xy in one launch.
     -> (bbox_pred [B,Q,10] polar, bbox_xy [B,Q,10] normalised xy)."""

@@ -17,6 +17,7 @@ What is different is the execution plan, designed for one MI355X per sample:
 There is no CPU fallback: inputs must live on the GPU and the HIP library must be built.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -27,7 +28,8 @@ from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
 from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add_ln, bev_sampling_fused, bev_sampling_multi_fused, box_prep,
                     quantize_values_i16,
-                    generator_fused, gru_gate_fused, layer_boundary_fused, mixing_fused, outproj_fused, pack_conv3x3_weight,
+                    generator_fused, gru_gate_fused, layer_boundary_fused, mixing_fused, mixing_sampled_fused, mixing_sampled_supported, outproj_fused,
+                    pack_conv3x3_weight,
                     pack_gemm_split_weight,
                     pe_head, refine_fused, row_gemm,
                     row_seg, rowgemm_launch, sampling4d_fused, sasa_fused, split_weight_f16, upsample2x_fused, value_proj_fused)
@@ -219,15 +221,19 @@ class RaCFormerSampling(nn.Module):
         # what a captured plan needs, whose warm-up and capture forwards all have to see the imposed choices)
         self.force_views_cyclic = False
         self._force_i = 0
+        self._last_forced = None
 
     def _next_forced(self):
+        self._last_forced = None
         if not self.force_views:
             return None
         if self.force_views_cyclic:
             v = self.force_views[self._force_i % len(self.force_views)]
             self._force_i += 1
-            return v
-        return self.force_views.pop(0)
+        else:
+            v = self.force_views.pop(0)
+        self._last_forced = v
+        return v
 
     def init_weights(self):
         bias = self.sampling_offset.bias.data.view(self.depth_num * self.num_groups * self.num_points, 3)
@@ -278,6 +284,21 @@ class RaCFormerSampling(nn.Module):
         if self.capture_loc is not None:
             self.capture_loc.append(res[1])
             return res if debug else res[0]
+        return res
+
+
+    def forward_into_mixing(self, query_ray, mlvl_feats, img_metas, d_region, linear_out, box_table, params, out_points=128):
+        """The sampling of forward() inside the AdaptiveMixing kernel (rac_mixing_sampled_fwd): -> the mixing output's f16 line
+        image for outproj_fused; the sampled features stay on chip.  Same hooks as forward() (capture_loc, force_views)."""
+        image_h, image_w, _ = img_metas[0]["img_shape"][0]
+        off, ray, sc = linear_out
+        res = mixing_sampled_fused(mlvl_feats, query_ray.contiguous(), off, ray, sc, img_metas[0]["time_diff"], img_metas[0]["lidar2img"],
+                                   self.num_frames, self.num_groups, self.num_points, self.depth_num, self.pc_range, d_region, image_h,
+                                   image_w, params, out_points=out_points, debug=self.capture_loc is not None, box_table=box_table,
+                                   view_in=self._next_forced())
+        if self.capture_loc is not None:
+            self.capture_loc.append(res[1])
+            return res[0]
         return res
 
 
@@ -906,6 +927,13 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # 30-query head fixture misses the literal 1e-3 on one query (1.1e-3; fp32: 5.5e-4) -- so the product keeps the reference's
         # storage and bench.py reports the int16 mode beside the headline.
         self.value_storage = "f32"
+        # True: the adaptive sampling runs INSIDE the mixing kernel (rac_mixing_sampled_fwd: the mixing workgroup of an item gathers its
+        # own 96 points, bit for bit what rac_sampling4d_fwd writes; the 88 MB [B,Q,G,T*P,C] tensor of a layer is never written).
+        # Correct (tests/test_fused_gpu.py::test_mixing_sampled_equals_sampling_then_mixing, every decoder-level parity test), but NOT
+        # faster: 181 us against 88 + 92 us for the two kernels -- a workgroup that also holds the mixing's operands can keep 8 taps
+        # in flight per lane on three workgroups per CU, the stand-alone gather 16 on five, and the texture path is
+        # latency x concurrency bound -- so the default stays False; the environment variable is the A/B switch of bench.py.
+        self.fuse_sampling_mixing = os.environ.get("RAC_FUSE_SAMPLING_MIXING", "0") == "1"
         # with "i16": the producers' own epilogues quantise (True) / separate rac_quant_i16_fwd launches over fp32 streams (False: tests)
         self.fused_q16_producers = True
         self._pack_cache = {}
@@ -946,6 +974,9 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
              2.0 * Qn * G_ * (Pin * C_ * C_ + 128 * Pin * C_),
              2.0 * Qn * G_ * (6 * 96 * C_ * C_ + 3 * 128 * 96 * C_) if split else 2.0 * Qn * G_ * (96 * C_ * C_ + 128 * 96 * C_),
              16 if split else 32),
+            ("mixing_sampled_fwd", "mixing_c64_f16x3_kernel<4> (the same two products; the workgroup gathers its own sampled features first: "
+             "rac_mixing_sampled_fwd)", 2.0 * Qn * G_ * (Pin * C_ * C_ + 128 * Pin * C_),
+             2.0 * Qn * G_ * (6 * 96 * C_ * C_ + 3 * 128 * 96 * C_), 16),
             ("mixing_generator_gemm", ("gemm_split_kernel (hand-written, 3 f16 products, loader waves + LDS-DMA ring)" if self.own_generator
                                        else "parameter_generator GEMM (hipBLASLt f16, K-concatenated hi/lo operands)") if split
              else "parameter_generator GEMM (rocBLAS fp32)",
@@ -1147,8 +1178,24 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             bev_sampling_fused(prepared["lss_value"], prepared["lss_hw"], qb, l_off, l_ray, l_sc, l_qu, time_diff,
                                lb.num_frames, lb.num_heads, lb.num_points, lb.depth_num, lb.pc_range, d_region,
                                box_table=table, out=bev[1])
-        sampled_feat = self._sample(qb, x1, mlvl_feats, img_metas, d_region, lin[0:3], table)
-        partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)
+        smp, mix = self.sampling, self.mixing
+        if (self.fuse_sampling_mixing and own_gen and mix.out_points == 128 and mix.eff_in_dim == 64 and mix.eff_out_dim == 64
+                and mix.in_points == smp.num_frames * smp.num_points * smp.depth_num and smp.num_groups == mix.n_groups
+                and mixing_sampled_supported(mlvl_feats, smp.num_frames, smp.num_points * smp.depth_num)):
+            # generator -> ONE kernel for the adaptive sampling and both mixings (the mixing workgroup gathers its own item while its
+            # parameters stream in: the [B,Q,G,T*P,C] tensor is never written) -> out_proj
+            params = generator_fused(x1_split, packs["gen_img"], mix.parameter_generator.bias, packs["gen_img_alpha"]).view(B, Q, -1)
+            img = smp.forward_into_mixing(qb, mlvl_feats, img_metas, d_region, lin[0:3], table, params, out_points=mix.out_points)
+            partials = outproj_fused(img, packs["out_w"], packs["out_slices"])
+            sampled_feat = None
+            if stages is not None:      # (the parity probes want the sampled features themselves: the stand-alone kernel, same choices)
+                image_h, image_w, _ = img_metas[0]["img_shape"][0]
+                sampled_feat = sampling4d_fused(mlvl_feats, qb, *lin[0:3], img_metas[0]["time_diff"], img_metas[0]["lidar2img"], smp.num_frames,
+                                                smp.num_groups, smp.num_points, smp.depth_num, smp.pc_range, d_region, image_h, image_w,
+                                                box_table=table, view_in=smp._last_forced)
+        else:
+            sampled_feat = self._sample(qb, x1, mlvl_feats, img_metas, d_region, lin[0:3], table)
+            partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)
         p_scale = packs["out_alpha"] if packs else 1.0
         # both BEV output projections in one launch
         proj = new(2, n, E)

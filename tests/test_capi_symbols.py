@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
     lib.rac_abi_version.restype = ctypes.c_int
-    assert lib.rac_abi_version() == 6
+    assert lib.rac_abi_version() == 7
 
 
 def declared_params():
@@ -57,7 +57,7 @@ def declared_params():
 def test_python_binding_covers_header(built_lib):
     from racformer_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib().rac_abi_version() == 6
+    assert _lib.lib().rac_abi_version() == 7
     kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f", ctypes.c_int64: "l"}
     for name, kinds in declared_params().items():
         got = [kind[a] for a in _lib.SIGNATURES[name][1]]

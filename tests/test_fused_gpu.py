@@ -127,6 +127,38 @@ def test_sampling4d_four_samples_per_forward_level0_beyond_2gib():
     assert err.median().item() < 5e-4 and (err > 5e-3).float().mean().item() < 0.01, (err.median().item(), (err > 5e-3).float().mean().item())
 
 
+@pytest.mark.parametrize("cfg", [syn.SMALL, syn.SMALL6, syn.F8, syn.F8_3CAM, _replace(syn.SMALL6, batch=2)],
+                         ids=["small", "small6", "f8", "f8_3cam", "small6_b2"])
+def test_mixing_sampled_equals_sampling_then_mixing(cfg):
+    """rac_mixing_sampled_fwd (the AdaptiveMixing kernel gathering its own sampled features) against rac_sampling4d_fwd followed by
+    rac_mixing_fwd on what that wrote: the out_proj operand image, the reported locations / camera choices and level weights are
+    the same BITS -- free-running and with camera choices imposed (view_in), on 3- and 6-camera rigs (points without any tap) and
+    with two samples per forward (the slot arithmetic of the second sample)."""
+    from racformer_amd.fused import mixing_fused, mixing_sampled_fused, sampling4d_fused
+    tr, sd, qb, qf, metas = _setup(cfg, 61, 62)
+    smp = tr.decoder.decoder_layer.sampling
+    feats = [f.to(DEV) for f in R.regroup_pyramid(syn.make_pyramid(cfg, 61), cfg.num_cams)]
+    B, Q, T, G = cfg.batch, cfg.num_query, cfg.num_frames, cfg.num_groups
+    P = cfg.num_points * cfg.img_depth_num
+    g = torch.Generator().manual_seed(7)
+    params = (torch.randn(B, Q, G * (64 * 64 + 128 * T * P), generator=g) * 0.2).to(DEV)
+    args = (T, G, cfg.num_points, cfg.img_depth_num, list(cfg.pc_range), cfg.d_region_list[3], cfg.image_hw[0], cfg.image_hw[1])
+    S = B * T * G
+    forced = torch.randint(0, cfg.num_cams, (S, Q, P), generator=g, dtype=torch.uint8).to(DEV)
+    with torch.no_grad():
+        lin = (smp.sampling_offset(qf.to(DEV)), smp.ray_points_offset(qf.to(DEV)), smp.scale_weights(qf.to(DEV)))
+        for view_in in (None, forced):
+            x, loc, w = sampling4d_fused(feats, qb.to(DEV), *lin, metas[0]["time_diff"], metas[0]["lidar2img"], *args, debug=True,
+                                         view_in=view_in)
+            want = mixing_fused(x, params, T * P, G, 128, split=True, f16x3=True)
+            got, loc2, w2 = mixing_sampled_fused(feats, qb.to(DEV), *lin, metas[0]["time_diff"], metas[0]["lidar2img"], *args, params,
+                                                 debug=True, view_in=view_in)
+            torch.cuda.synchronize()
+            assert torch.equal(loc, loc2) and torch.equal(w, w2)
+            assert got.shape == want.shape and torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+    assert float(want.float().abs().max()) > 0.1            # (not a comparison of zeros)
+
+
 @pytest.mark.parametrize("cfg", [syn.SMALL, syn.F8])
 def test_bev_sampling_fused(cfg):
     tr, sd, qb, qf, metas = _setup(cfg, 31, 32)

@@ -399,3 +399,14 @@ def test_decoder_small_batch2_vs_oracle():
     (cls, box, _), _ = run_with_reference_views(lambda force: run_decoder_gpu(cfg, seed, wseed, force), oviews, "small6 batch 2")
     assert tuple(cls.shape[:2]) == (6, 2)
     decoder_parity(cls, box, ocls, obox, what="small6 batch 2 vs oracle", tail_budget=None)
+
+
+@pytest.mark.parametrize("cfg", [syn.F8, syn.F8_3CAM], ids=["f8", "f8_3cam"])
+def test_decoder_sampling_inside_the_mixing_kernel_same_bits(cfg):
+    """`fuse_sampling_mixing = True` (rac_mixing_sampled_fwd: the mixing workgroup gathers its own sampled features) against the default
+    plan (rac_sampling4d_fwd -> rac_mixing_fwd): six free-running layers, the same bits -- class scores, boxes, camera choices.  (The
+    fused launch is not the default because it is not faster; every parity statement about the default plan therefore
+    holds for it as well.)"""
+    a = run_decoder_gpu(cfg, 27, 28, fuse_sampling_mixing=False)
+    b = run_decoder_gpu(cfg, 27, 28, fuse_sampling_mixing=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])

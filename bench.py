@@ -519,7 +519,16 @@ def main():
     # mixing half moves: the item's generated parameters (fp32) in, the out_proj operand image (f16 hi + lo = 4 bytes per value) out
     Pin_ = cfg.num_points * cfg.num_frames * cfg.img_depth_num
     mix_bytes = cfg.batch * cfg.num_query * cfg.num_groups * ((cfg.channels * cfg.channels + 128 * Pin_) * 4 + 128 * cfg.channels * 4)
-    per_launch = [msmv_algorithmic_bytes(loc, shapes, elt, 0 if fused_sm else out_elems) for loc, shapes in cap.captured]
+    # The unit the roofline prices is ONE DECODER LAYER's sampling.  The layer may issue it as several launches over ranges of the
+    # queries (the two-half pipeline of the decoder layer: the second half's gather runs beside the first half's mixing): their
+    # locations are put together again and the SURVEY 8(d) formula -- whose per-level cap is "the level once" -- is applied to the
+    # layer as a whole, against the SUM of the launches' durations.  (Applied per half-launch the caps of the coarse levels would count
+    # twice and inflate the algorithmic bytes by a third.)
+    launches_per_layer = max(1, len(cap.captured) // cfg.num_layers)
+    assert len(cap.captured) == launches_per_layer * cfg.num_layers, (len(cap.captured), cfg.num_layers)
+    layers_loc = [(torch.cat([cap.captured[i * launches_per_layer + j][0] for j in range(launches_per_layer)], dim=1),
+                   cap.captured[i * launches_per_layer][1]) for i in range(cfg.num_layers)]
+    per_launch = [msmv_algorithmic_bytes(loc, shapes, elt, 0 if fused_sm else out_elems) for loc, shapes in layers_loc]
     if fused_sm:
         per_launch = [(b_ + mix_bytes, f_) for b_, f_ in per_launch]
     b_alg = float(np.mean([b for b, _ in per_launch]))
@@ -528,6 +537,8 @@ def main():
     n_pts = S * cfg.num_query * P
     b_alg_closed = sum(min(n_pts * 4 * c * elt, s_ * n_ * h * w * c * elt) for (s_, n_, h, w, c) in full_shapes) \
         + n_pts * 3 * 4 + n_pts * cfg.num_levels * 4 + (mix_bytes if fused_sm else out_elems * 4)
+    launch_ms = msmv_ms                                     # mean duration of ONE launch
+    msmv_ms = msmv_ms * launches_per_layer if msmv_ms else None      # ... and of one layer's sampling
     achieved = b_alg / (msmv_ms * 1e-3) / 1e9 if msmv_ms else None
     traffic, traffic_src = pmc_traffic("mixing_c64_f16x3_kernel<4>", "racformer_amd/csrc/mixing.hip", args.config) if fused_sm else \
         pmc_traffic("sampling4d_c64_kernel", "racformer_amd/csrc/sampling_fused.hip", args.config)
@@ -608,7 +619,9 @@ def main():
                      "limiter": "the CU's texture path (1.41 GB of tap requests through L1 / L2) beside the 0.35 GB parameter / output stream of the "
                                 "mixing half" if fused_sm else "L1/L2 gather-request rate (HBM-side traffic is below the algorithmic bytes)",
                      "sampling_inside_mixing_kernel": fused_sm,
-                     "avg_launch_ms": msmv_ms, "launches_per_step": len(cap.captured),
+                     "avg_launch_ms": launch_ms, "launches_per_step": len(cap.captured), "launches_per_layer": launches_per_layer,
+                     "avg_layer_ms": msmv_ms,
+                     "roofline_unit_note": "one decoder layer's sampling (all its launches: algorithmic bytes of the layer / sum of their durations)",
                      "timed_in": "HIP events on the launch stream inside the timed region" if captured is None else
                                  f"HIP events on the launch stream over {args.steps} eager steps of the same work right behind the "
                                  "timed region (a captured graph holds no event brackets)",

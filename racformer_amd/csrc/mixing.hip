@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 3) void mixing_c64_f16x3_kernel(const MixSampA
         rac_f4 v = {0.f, 0.f, 0.f, 0.f};
         if (c4 * 4 + 3 < P) {
             if (s_vec) {
-                v = rac_ld4(src);
+                v = rac_ld4_stream(src);
             } else {
                 v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
             }
@@ -408,14 +408,14 @@ __global__ __launch_bounds__(256, 3) void mixing_c64_f16x3_kernel(const MixSampA
             const int i = tid + 256 * k, r = i >> 4, c4 = i & 15;
             vx[k] = (rac_f4){0.f, 0.f, 0.f, 0.f};
             if (r < P)
-                vx[k] = rac_ld4(gx + r * MIX_C + c4 * 4);
+                vx[k] = rac_ld4_stream(gx + r * MIX_C + c4 * 4);
         }
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            mv[ks][j] = gM[(32 * ks + 8 * lk + j) * MIX_C + 16 * wave + li];
+            mv[ks][j] = RAC_STREAM_NT ? __builtin_nontemporal_load(gM + (32 * ks + 8 * lk + j) * MIX_C + 16 * wave + li) : gM[(32 * ks + 8 * lk + j) * MIX_C + 16 * wave + li];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
         vs0[k] = load_S(0, k);

@@ -47,6 +47,30 @@ __device__ __forceinline__ rac_f4 rac_ld4(const float *p)
 {
     return *reinterpret_cast<const rac_f4 *>(p);
 }
+// Streaming forms for data a kernel touches exactly once (the pyramid transpose, the mixing kernel's operands and output): non-temporal,
+// so that the lines do not displace what the gather kernels of the samples running beside this one keep re-reading from L2
+// (several plans in flight, racformer_amd/graph.py).  RAC_STREAM_NT = 0: plain accesses (A/B builds).
+#ifndef RAC_STREAM_NT
+#define RAC_STREAM_NT 1
+#endif
+typedef float rac_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rac_f4 rac_ld4_stream(const float *p)
+{
+#if RAC_STREAM_NT
+    const rac_f4v v = __builtin_nontemporal_load(reinterpret_cast<const rac_f4v *>(p));
+    return rac_f4{v.x, v.y, v.z, v.w};
+#else
+    return rac_ld4(p);
+#endif
+}
+__device__ __forceinline__ void rac_st4_stream(float *p, const rac_f4 v)
+{
+#if RAC_STREAM_NT
+    __builtin_nontemporal_store((rac_f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<rac_f4v *>(p));
+#else
+    *reinterpret_cast<rac_f4 *>(p) = v;
+#endif
+}
 // 4 bf16 (8 bytes) -> 4 floats
 __device__ __forceinline__ rac_f4 rac_ld4(const unsigned short *p)
 {

@@ -77,7 +77,7 @@ struct RegroupArgs {
 template <typename OT>
 __device__ __forceinline__ void regroup_store4(OT *p, const rac_f4 v);
 template <>
-__device__ __forceinline__ void regroup_store4<float>(float *p, const rac_f4 v) { *reinterpret_cast<rac_f4 *>(p) = v; }
+__device__ __forceinline__ void regroup_store4<float>(float *p, const rac_f4 v) { rac_st4_stream(p, v); }
 template <>
 __device__ __forceinline__ void regroup_store4<unsigned short>(unsigned short *p, const rac_f4 v)
 {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void regroup_multi_kernel(const RegroupArgs a)
         const int c = c0 + 4 * cq + i, hw = hw0 + 4 * hq;
         v[i] = (rac_f4){0.f, 0.f, 0.f, 0.f};
         if (c < C && hw < HW)                            // (HW % 4 == 0: a float4 never straddles the end)
-            v[i] = rac_ld4(src + (size_t)c * HW + hw);
+            v[i] = rac_ld4_stream(src + (size_t)c * HW + hw);
     }
     // 4 x 4 register transpose -> LDS rows = pixels
     *reinterpret_cast<rac_f4 *>(&tile[4 * hq + 0][4 * cq]) = (rac_f4){v[0].x, v[1].x, v[2].x, v[3].x};

@@ -21,7 +21,7 @@ def _rows(t, width, what):
     """[B,Q,width] view with unit last stride -> (pointer, row stride in floats)."""
     if not t.is_cuda or t.dtype != torch.float32:
         raise RuntimeError(f"racformer_amd.{what}: expected a float32 CUDA tensor")
-    if t.shape[-1] != width or t.stride(-1) != 1 or (t.dim() == 3 and t.stride(0) != t.shape[1] * t.stride(1)):
+    if t.shape[-1] != width or t.stride(-1) != 1 or (t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)):
         raise RuntimeError(f"racformer_amd.{what}: expected [B,Q,{width}] rows with unit inner stride")
     return _lib.ptr(t), int(t.stride(-2))
 
@@ -232,20 +232,25 @@ def sasa_fused(qkv, tau, query_bbox, num_heads, pc_range, box_table=None):
     return out
 
 
-def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5, split=False, param_scale=1.0, f16x3=False):
+def mixing_fused(x, params, in_points, n_groups, out_points=128, eps=1e-5, split=False, param_scale=1.0, f16x3=False, out=None):
     """x [B,Q,G,P,64] (contiguous), params [B,Q,G*(64*64+128*P)] (unit inner stride) ->
     relu(LN(S @ relu(LN(x @ M)))) as [B,Q,G*128*64], ready for out_proj.
     ``split=True``: instead returns the f16 line image [B*Q, G*256, hi 32 | lo 32] of the same values * SPLIT_ACT_SCALE
     (A operand of rac_outproj_fwd: every value stored once as hi + lo).
     ``param_scale``: factor applied to every parameter on load (the power-of-two alpha of a split generator GEMM).
-    ``f16x3``: run the two products as 3-product split-precision f16 MFMAs (RAC_MIX_F16X3) instead of f32-input MFMAs."""
+    ``f16x3``: run the two products as 3-product split-precision f16 MFMAs (RAC_MIX_F16X3) instead of f32-input MFMAs.
+    ``out``: write into this tensor (a row range of a larger image) instead of allocating."""
     _lib.require_gpu(x, what="mixing_fused")
     B, Q, G, P, C = x.shape
     if G != n_groups or P != in_points or x.dtype != torch.float32:
         raise RuntimeError("mixing_fused: x must be float32 [B,Q,G,P,64]")
     width = G * (C * C + out_points * P)
     p_par, ld_par = _rows(params, width, "mixing_fused(params)")
-    if split:
+    if out is not None:
+        want = ((B * Q, G * out_points * C // 32, 64), torch.float16) if split else ((B, Q, G * out_points * C), torch.float32)
+        if tuple(out.shape) != want[0] or out.dtype != want[1] or not out.is_contiguous() or not out.is_cuda:
+            raise RuntimeError(f"mixing_fused: out must be a contiguous CUDA {want[1]} tensor of shape {want[0]}")
+    elif split:
         out = torch.empty(B * Q, G * out_points * C // 32, 64, device=x.device, dtype=torch.float16)
     else:
         out = torch.empty(B, Q, G * out_points * C, device=x.device, dtype=torch.float32)
@@ -861,3 +866,4 @@ def decode_fused(cls_scores, bbox_preds, max_num, post_center_range, score_thres
                                    float(score_threshold or 0.0), int(bool(score_threshold)), _lib.stream_ptr())
     _lib.check(rc, "rac_decode_fwd")
     return out
+

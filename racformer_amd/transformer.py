@@ -788,6 +788,9 @@ class AdaptiveMixing(nn.Module):
         return dict(gen_w=gen_w, gen_alpha=gen_alpha, gen_img=gimg, gen_img_alpha=gimg_alpha, out_w=ow, out_alpha=out_alpha,
                     out_slices=K // self.OUT_SLICE_K)
 
+    def fused_supported_shape(self, in_points):
+        return self.eff_in_dim == 64 and self.eff_out_dim == 64 and self.out_points == 128 and in_points == self.in_points <= 96
+
     def out_proj_partials(self, x, query, out_proj_split, params=None, packs=None, query_split=None):
         """Fused plan without the epilogue: generator GEMM -> MFMA mixing kernel -> split-K batched
         out_proj.  Returns the S partial products [S, B*Q, query_dim]; their sum + out_proj.bias + query

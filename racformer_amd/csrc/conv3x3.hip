@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ conv
+RAC_CLOCK_DECL(conv3x3)
+RAC_CLOCK_READER(conv3x3)
 struct ConvArgs {
     const uint4 *xs;
     const uint4 *ws;
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
     CV_LSTORE(0);
     CV_GLOAD(KS > 1 ? 1 : 0);
     __syncthreads();
+    RAC_CLOCK_BEGIN();
 #if CV_SPREAD_STAGING
     // Round 4: the step's staging traffic -- eight LDS writes of tile ks+1 and the eight global loads of tile ks+2 that re-use
     // their registers -- is dealt out over the eight MFMA groups of the step, one (write, load) pair per group, and the A
@@ -357,6 +360,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
     }
 #endif
 
+    RAC_CLOCK_END(conv3x3, blockIdx.x);
     // epilogue: undo the two power-of-two scalings, add the bias (per channel, or per pixel and channel), channel-last store.
     // The weights are the MFMA's A operand, so a 16x16 accumulator tile has its PIXEL on the lane (column li) and four
     // consecutive output CHANNELS (rows 4 lk + r) in the lane's registers: one 16-byte store (and one 16-byte bias load) per

@@ -44,6 +44,10 @@ typedef float gs_f4 __attribute__((ext_vector_type(4)));
 #define GS_STAGES 3
 #define GS_PIECES_PER_LOADER 12            /* 48 one-KB LDS-DMA pieces per stage, four loader waves */
 
+RAC_CLOCK_DECL(outproj)
+RAC_CLOCK_READER(outproj)
+RAC_CLOCK_DECL(generator)
+RAC_CLOCK_READER(generator)
 struct GemmSplitArgs {
     const char *x;      // X image
     const char *w;      // W image
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(768, 1) void gemm_split_kernel(const GemmSplitArgs 
     }
     gs_f4 acc[4][4];                                // [W tile][X tile]: rows = features, cols = X rows
     __builtin_amdgcn_s_barrier();                   // step 0 has landed
+    RAC_CLOCK_BEGIN();
     int gs = 0;
     for (int ti = 0; ti < my_tiles; ++ti) {
         const int t = t_begin + ti;
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(768, 1) void gemm_split_kernel(const GemmSplitArgs 
             }
         }
     }
+    RAC_CLOCK_END(outproj, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ W-stationary kernel
@@ -334,6 +340,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void generator_ws_k
 
     // fragment read: row r = 16j + li of the stage, chunk c = 8 ks + (hi: lk, lo: 4 + lk), LDS slot c ^ (r & 15) = c ^ li
     // A trip of the outer loop is GW_UNROLL stages with compile-time ring slots.
+    RAC_CLOCK_BEGIN();
     for (int st0 = 0; st0 < nstages; st0 += GW_UNROLL) {
 #pragma unroll
     for (int u = 0; u < GW_UNROLL; ++u) {
@@ -444,6 +451,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void generator_ws_k
         __builtin_amdgcn_s_barrier();
     }
     }
+    RAC_CLOCK_END(generator, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- weight packer: nn.Linear weight [N][K] f32 -> image [N][K/32][hi 32 | lo 32] f16 of weight * scale -------------------

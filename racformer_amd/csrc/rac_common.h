@@ -170,3 +170,36 @@ __device__ __forceinline__ uint2 rac_q16x4(float x, float y, float z, float w, f
     o.y = ((unsigned)rac_q16(z, up) & 0xffffu) | ((unsigned)rac_q16(w, up) << 16);
     return o;
 }
+
+// Diagnostic builds only (-DRAC_CLOCK_STAMPS through tools/build_variant.sh; tools/kernel_clock.py): the clock a matrix-core kernel
+// holds under its own load.  Wave 0 of every workgroup stamps s_memtime (shader clock ticks) and s_memrealtime (100 MHz) once
+// around its main loop; in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, 'DVFS give-back' item 6).
+// The stamps go to a device array of their own that nothing else reads; not part of the product library or its ABI.
+#if defined(RAC_CLOCK_STAMPS) && defined(RAC_DIAGNOSTIC_BUILD)
+#define RAC_CLOCK_WGS 1024
+#define RAC_CLOCK_DECL(name) __device__ unsigned long long name##_clock_buf[RAC_CLOCK_WGS * 4];
+#define RAC_CLOCK_BEGIN() const unsigned long long clk_t0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime()
+#define RAC_CLOCK_END(name, wg)                                                  \
+    do {                                                                         \
+        if ((threadIdx.x & 63) == 0 && threadIdx.x < 64 && (wg) < RAC_CLOCK_WGS) { \
+            name##_clock_buf[(wg) * 4 + 0] = clk_t0_;                            \
+            name##_clock_buf[(wg) * 4 + 1] = clk_r0_;                            \
+            name##_clock_buf[(wg) * 4 + 2] = __builtin_amdgcn_s_memtime();       \
+            name##_clock_buf[(wg) * 4 + 3] = __builtin_amdgcn_s_memrealtime();   \
+        }                                                                        \
+    } while (0)
+#define RAC_CLOCK_READER(name)                                                                                           \
+    extern "C" int rac_dbg_clock_##name(unsigned long long *host_out, int n_wgs)                                         \
+    {                                                                                                                    \
+        if (n_wgs > RAC_CLOCK_WGS)                                                                                       \
+            n_wgs = RAC_CLOCK_WGS;                                                                                       \
+        hipDeviceSynchronize();                                                                                          \
+        return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(name##_clock_buf), sizeof(unsigned long long) * 4 * n_wgs, 0, \
+                                        hipMemcpyDeviceToHost);                                                          \
+    }
+#else
+#define RAC_CLOCK_DECL(name)
+#define RAC_CLOCK_BEGIN()
+#define RAC_CLOCK_END(name, wg)
+#define RAC_CLOCK_READER(name)
+#endif

@@ -4,6 +4,7 @@ import glob
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -75,3 +76,12 @@ def test_argument_errors_need_no_gpu(built_lib):
     rc = lib.rac_msmv_fwd(one, hw, 1, ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8),
                           1, 1, 1, 129, 64, 0, 0, 1, 1, None)
     assert rc == -1 and b"num_point exceed limits" in lib.rac_last_error()
+
+
+def test_graft_entry_build_accepts_the_trees_own_library():
+    """__graft_entry__.build() (the driver's "does it build" check) ends with an ABI-version check against include/racformer_hip.h:
+    it must pass on the in-tree build (round 4 caught a hard-coded version there that had gone stale)."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    g = importlib.import_module("__graft_entry__")
+    g.build()

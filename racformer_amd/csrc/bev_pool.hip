@@ -29,7 +29,13 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_kernel(int c, int n_interval
     // at once.  An interval is a serial sum (one writer per output element), and the f8 Lift-Splat frustum has intervals of up to
     // 416 points next to a mean of 26: with index -> depth -> row as a dependent chain per point the longest interval alone took
     // most of the launch (143 us for 343 MB of L2-resident rows).  Same order of additions as before.
-    for (int c0 = ln * 4; c0 < c; c0 += LANES * 4) {
+    // Round 5: the channel pass is a loop ALL lanes of the group take (cb is group-uniform) and only the row load / store is
+    // predicated on the lane's own channel quad: with `for (c0 = ln * 4; c0 < c; ...)` the lanes whose quad lies past c (any
+    // c % (4 * LANES) != 0, e.g. c = 80 on 16 lanes) were masked off for the pass, never fetched their point of the chunk, and a
+    // shuffle from a disabled lane reads 0 -- those points silently dropped out of the sum.
+    for (int cb = 0; cb < c; cb += LANES * 4) {
+        const int c0 = cb + ln * 4;
+        const bool mine = c0 < c;
         rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int base = 0; base < len; base += LANES) {
             const int n = min(LANES, len - base);
@@ -45,8 +51,9 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_kernel(int c, int n_interval
                 float d[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    f[u] = rac_ld4(feat + (size_t)__shfl(my_rf, i + u, LANES) * c + c0);
+                    const size_t row = (size_t)__shfl(my_rf, i + u, LANES) * c;
                     d[u] = __shfl(my_d, i + u, LANES);
+                    f[u] = mine ? rac_ld4(feat + row + c0) : rac_f4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -54,12 +61,14 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_kernel(int c, int n_interval
                 }
             }
             for (; i < n; ++i) {
-                const rac_f4 f = rac_ld4(feat + (size_t)__shfl(my_rf, i, LANES) * c + c0);
+                const size_t row = (size_t)__shfl(my_rf, i, LANES) * c;
                 const float d = __shfl(my_d, i, LANES);
+                const rac_f4 f = mine ? rac_ld4(feat + row + c0) : rac_f4{0.f, 0.f, 0.f, 0.f};
                 acc.x += f.x * d; acc.y += f.y * d; acc.z += f.z * d; acc.w += f.w * d;
             }
         }
-        *reinterpret_cast<rac_f4 *>(out + (size_t)ranks_bev[start] * c + c0) = acc;
+        if (mine)
+            *reinterpret_cast<rac_f4 *>(out + (size_t)ranks_bev[start] * c + c0) = acc;
     }
 }
 
@@ -128,8 +137,11 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_kernel(int c, int n_interval
         }
     }
     // feature gradients: accumulated over the interval, one writer per element
+    // (group-uniform channel pass, predicated row access: as in the forward kernel)
     if (live)
-        for (int c0 = ln * 4; c0 < c; c0 += LANES * 4) {
+        for (int cb = 0; cb < c; cb += LANES * 4) {
+            const int c0 = cb + ln * 4;
+            const bool mine = c0 < c;
             rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int base = 0; base < len; base += LANES) {
                 const int n = min(LANES, len - base);
@@ -145,8 +157,9 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_kernel(int c, int n_interval
                     float d[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        g[u] = rac_ld4(out_grad + (size_t)__shfl(my_rb, i + u, LANES) * c + c0);
+                        const size_t row = (size_t)__shfl(my_rb, i + u, LANES) * c;
                         d[u] = __shfl(my_d, i + u, LANES);
+                        g[u] = mine ? rac_ld4(out_grad + row + c0) : rac_f4{0.f, 0.f, 0.f, 0.f};
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -154,12 +167,14 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_kernel(int c, int n_interval
                     }
                 }
                 for (; i < n; ++i) {
-                    const rac_f4 g = rac_ld4(out_grad + (size_t)__shfl(my_rb, i, LANES) * c + c0);
+                    const size_t row = (size_t)__shfl(my_rb, i, LANES) * c;
                     const float d = __shfl(my_d, i, LANES);
+                    const rac_f4 g = mine ? rac_ld4(out_grad + row + c0) : rac_f4{0.f, 0.f, 0.f, 0.f};
                     acc.x += g.x * d; acc.y += g.y * d; acc.z += g.z * d; acc.w += g.w * d;
                 }
             }
-            *reinterpret_cast<rac_f4 *>(feat_grad + (size_t)rf * c + c0) = acc;
+            if (mine)
+                *reinterpret_cast<rac_f4 *>(feat_grad + (size_t)rf * c + c0) = acc;
         }
 }
 

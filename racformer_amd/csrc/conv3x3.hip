@@ -408,14 +408,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
             for (int mm = 0; mm < 4; ++mm) {
                 const int m = 4 * half + mm, p = 128 * wm + 16 * m + li;
                 cv_f4 v[4];
-                float bm = 0.f;
+                unsigned bm = 0u;
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
                     v[nn] = cv_fma4(acc[m][nn], unscale, pb[mm][nn]);
-                    bm = fmaxf(bm, fmaxf(fmaxf(fabsf(v[nn][0]), fabsf(v[nn][1])), fmaxf(fabsf(v[nn][2]), fabsf(v[nn][3]))));
+                    bm = max(bm, rac_absbits4(v[nn][0], v[nn][1], v[nn][2], v[nn][3]));
                 }
-                bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-                bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+                bm = max(bm, (unsigned)__shfl_xor((int)bm, 16, 64));
+                bm = max(bm, (unsigned)__shfl_xor((int)bm, 32, 64));
                 float up, dn;
                 rac_q16_factors(bm, up, dn);
                 if (p < prows) {

@@ -18,10 +18,10 @@ __global__ __launch_bounds__(256) void quant_i16_block64_kernel(const float *__r
     const long stride = (long)gridDim.x * 16;
     for (long b = (long)blockIdx.x * 16 + (threadIdx.x >> 4); b < blocks; b += stride) {
         const rac_f4 x = rac_ld4(v + b * 64 + lane16 * 4);
-        float m = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+        unsigned m = rac_absbits4(x.x, x.y, x.z, x.w);
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1)
-            m = fmaxf(m, __shfl_xor(m, off, 64));
+            m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
         float up, dn;
         rac_q16_factors(m, up, dn);
         const uint2 o = rac_q16x4(x.x, x.y, x.z, x.w, up);

@@ -150,11 +150,25 @@ __device__ __forceinline__ void rac_split_f16(float v, _Float16 &hi, _Float16 &l
 
 // int16 block storage of a BEV value stream (quant.hip; the q16 epilogues of conv3x3.hip and value_proj.hip): value = q * dn with
 // dn = 2^(e - 14), e = floor(log2(max |block|)).  Exponent arithmetic only: eb = biased exponent of the block maximum, clamped so that
-// both powers of two are normal floats (an all-zero / denormal block gets q = 0 with the smallest scale; inf / nan saturate).
-__device__ __forceinline__ void rac_q16_factors(float block_max, float &up, float &dn)
+// both powers of two are normal floats (an all-zero / denormal block gets q = 0 with the smallest scale).  A block whose maximum is
+// inf or NaN gets a NaN scale: every value of the block reads back as NaN, as it would propagate through the fp32 stream (a
+// diverged model must not look healthy because its storage saturates).  The block maximum is taken on the BIT PATTERNS
+// of |x| as unsigned integers (rac_absbits / max): monotonic for finite values, and a NaN (pattern above inf's) wins, where fmaxf
+// would drop it.
+__device__ __forceinline__ unsigned rac_absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned rac_absbits4(float x, float y, float z, float w)
 {
-    int eb = (int)((__float_as_uint(block_max) >> 23) & 255u);
-    eb = eb < 15 ? 15 : (eb > 254 ? 254 : eb);
+    return max(max(rac_absbits(x), rac_absbits(y)), max(rac_absbits(z), rac_absbits(w)));
+}
+__device__ __forceinline__ void rac_q16_factors(unsigned block_max_bits, float &up, float &dn)
+{
+    int eb = (int)((block_max_bits >> 23) & 255u);
+    if (eb == 255) {
+        up = 0.f;
+        dn = __uint_as_float(0x7fc00000u);
+        return;
+    }
+    eb = eb < 15 ? 15 : eb;
     up = __uint_as_float((unsigned)(268 - eb) << 23);      // 2^(14 - (eb - 127)): |x| * up < 2^15
     dn = __uint_as_float((unsigned)(eb - 14) << 23);       // 2^((eb - 127) - 14)
 }

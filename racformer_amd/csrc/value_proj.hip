@@ -185,19 +185,19 @@ __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs 
         }
         // ---- epilogue: C/D layout col = li (pixel), rows 4 lk + r = four consecutive features: one 16-byte store
         if (QOUT) {
-            float *pmax = reinterpret_cast<float *>(lds + VP_LDS);          // [8 waves][32 pixels]
+            unsigned *pmax = reinterpret_cast<unsigned *>(lds + VP_LDS);          // [8 waves][32 pixels]
             vp_f4 v[2][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float a = salpha[16 * j + li];
-                float bm = 0.f;
+                unsigned bm = 0u;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     v[j][t] = __builtin_elementwise_fma(acc[t][j], (vp_f4){a, a, a, a}, addv[j][t]);
-                    bm = fmaxf(bm, fmaxf(fmaxf(fabsf(v[j][t][0]), fabsf(v[j][t][1])), fmaxf(fabsf(v[j][t][2]), fabsf(v[j][t][3]))));
+                    bm = max(bm, rac_absbits4(v[j][t][0], v[j][t][1], v[j][t][2], v[j][t][3]));
                 }
-                bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-                bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+                bm = max(bm, (unsigned)__shfl_xor((int)bm, 16, 64));
+                bm = max(bm, (unsigned)__shfl_xor((int)bm, 32, 64));
                 if (lk == 0)
                     pmax[wave * VP_ROWS + 16 * j + li] = bm;
             }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, 1) void value_proj_kernel(const ValueProjArgs 
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = 16 * j + li;
-                const float bm = fmaxf(pmax[wave * VP_ROWS + r], pmax[(wave ^ 1) * VP_ROWS + r]);
+                const unsigned bm = max(pmax[wave * VP_ROWS + r], pmax[(wave ^ 1) * VP_ROWS + r]);
                 float up, dn;
                 rac_q16_factors(bm, up, dn);
                 if (gp + r < mend) {

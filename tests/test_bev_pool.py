@@ -49,13 +49,17 @@ def test_hip_known_answer(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c", [256, 128, 64, 6])
-def test_hip_vs_oracle_random(c):
+@pytest.mark.parametrize("grid", [12, 3])
+@pytest.mark.parametrize("c", [256, 128, 64, 6, 32, 80, 192, 320, 4])
+def test_hip_vs_oracle_random(c, grid):
     """LSS-shaped random case: B=1, N=2 cams, D=8 depth bins, 6x10 feature map -> 12x12 BEV grid; ragged
-    intervals including empty BEV cells; c=6 exercises the scalar-channel fallback."""
+    intervals including empty BEV cells; c=6 exercises the scalar-channel fallback.  c = 32 / 80 / 192 / 320 / 4 are not
+    multiples of 4 x (lanes of a group): the last channel pass leaves part of the group without a channel quad, and with the
+    3x3 grid the intervals (mean 64 points) are longer than the lanes that still have one (BEVDet's numC_Trans = 80 is such
+    a width; round 4's kernel dropped those points)."""
     from racformer_amd.bev_pool import bev_pool_v2, intervals_from_ranks
     rng = np.random.default_rng(c)
-    B, N, D, H, W, Z, Y, X = 1, 2, 8, 6, 10, 1, 12, 12
+    B, N, D, H, W, Z, Y, X = 1, 2, 8, 6, 10, 1, grid, grid
     depth = torch.from_numpy(rng.random((B, N, D, H, W), dtype=np.float32))
     feat = torch.from_numpy(rng.standard_normal((B, N, H, W, c), dtype=np.float32))
     n_pts = B * N * D * H * W

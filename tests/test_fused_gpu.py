@@ -697,6 +697,28 @@ def test_value_proj_q16_epilogue_is_the_quantiser_of_the_fp32_output(F_, H, W):
     assert torch.equal(sc2, wsc2) and torch.equal(q2, wq2)
 
 
+def test_quantiser_propagates_non_finite_blocks():
+    """rac_quant_i16_fwd: a (pixel, head) block that holds an inf or a NaN gets a NaN scale, so every value of that block reads
+    back as NaN -- as it would travel through the fp32 stream -- instead of saturating to a large finite number; the
+    blocks beside it are untouched, and finite blocks keep |x - q * scale| <= scale / 2."""
+    from racformer_amd.fused import quantize_values_i16
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(2, 5, 4, 64, generator=g) * torch.exp(torch.randn(2, 5, 4, 1, generator=g) * 4.0)
+    v[0, 1, 2, 7] = float("nan")
+    v[1, 0, 0, 63] = float("inf")
+    v[1, 4, 3, 0] = float("-inf")
+    v[0, 3, 1] = 0.0
+    q, sc = quantize_values_i16(v.to(DEV))
+    back = (q.float() * sc.unsqueeze(-1)).cpu()
+    bad = torch.zeros(2, 5, 4, dtype=torch.bool)
+    bad[0, 1, 2] = bad[1, 0, 0] = bad[1, 4, 3] = True
+    assert torch.isnan(sc.cpu())[bad].all() and torch.isfinite(sc.cpu())[~bad].all()
+    assert torch.isnan(back[bad]).all()
+    ok = ~bad
+    assert ((back[ok] - v[ok]).abs() <= 0.5 * sc.cpu()[ok].unsqueeze(-1) + 0.0).all()
+    assert int(q.cpu()[0, 3, 1].abs().max()) == 0
+
+
 def test_head_finish_kernel_matches_torch():
     """rac_head_finish_fwd against the reference's own element-wise tail (nan_to_num of both stacked outputs,
     racformer_transformer.py:58; centre scaling + column order, racformer_head.py:124-131), incl. NaN and +-inf entries:

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RAC_ABI_VERSION 7
+#define RAC_ABI_VERSION 8
 #define RAC_MAX_LEVELS 8
 #define RAC_MAX_POINTS 128 /* same limit as the reference, msmv_sampling_forward.cu:21 */
 
@@ -453,6 +453,77 @@ int rac_bev_pool_v2_bwd(const float *out_grad, float *depth_grad, float *feat_gr
                         const float *feat, const int32_t *ranks_depth, const int32_t *ranks_feat,
                         const int32_t *ranks_bev, const int32_t *interval_lengths, const int32_t *interval_starts,
                         int c, int n_intervals, void *stream);
+
+/* ---- Round 5: the ConvGRU branch of RadarBEVTemporalEncoder without library convolutions -------------------------------------
+ * (models/racformer_transformer.py:645-656 inner_forward, :674-693 ConvGRU, :705-720 ConvGRUCell)
+ *
+ * rac_conv_direct_fwd: a 3x3 convolution (stride 1 or 2, pad 1) for the SMALL maps of that branch (64 x 64 x 64 channels, one
+ * frame at a time through the recurrence), with the split-precision arithmetic of rac_conv3x3_fwd (three f16 MFMA products of
+ * hi / lo operands, fp32 accumulate: fp32-convolution accuracy).  Unlike rac_conv3x3_fwd nothing is staged through LDS and no
+ * workgroup barrier is executed: a wave owns 16 output pixels x (16 * tiles) output channels and loads its MFMA fragments
+ * straight from the activation image / weight image (both L2-resident at these sizes) through a register ring several K steps
+ * ahead -- these launches are latency-bound chains, not throughput kernels.
+ *
+ *   in_img   f16 [frames][H+2][W+2][in_chunks_total][hi 32 | lo 32]  zero border; K runs over chunks in_chunk0 .. +chunks-1
+ *            (chunks == 0: no convolution, the accumulators stay zero -- the recurrence's first step, h_0 = 0)
+ *   ws       f16 [9 taps][chunks][Cout][hi 32 | lo 32]  (racformer_amd.fused.pack_conv3x3_weight), w_alpha = its 2^-s
+ *   scales   an image's power-of-two scale is rac's act_scale(bound) with bound = mul * (*amax) + add  (amax may be NULL):
+ *            a DEVICE word plus host constants, so that a bound derived from the weights follows the measured input maximum
+ *   frame maps  frame(n) = (n / live) * stride + n % live + first:  the n-th processed frame inside a [groups][stride] stack
+ * mode RAC_CD_IMAGE : out_img <- (conv + bias) as an activation image [frames][OH+2][OW+2][out_chunks_total][hi|lo], channels
+ *                     out_chunk0 * 32 .. (interior pixels only; the caller zeroed the border once)
+ * mode RAC_CD_F32   : out_f32 [N][OH*OW][Cout] channel-last <- conv + bias + pixel_map[OH*OW][Cout] (either may be NULL)
+ * mode RAC_CD_GRU   : Cout = 3 * 64 gate channels (z | r | candidate); pre = conv(h_prev image) + xpart[frame][pixel][192];
+ *                     z = sigmoid, r = sigmoid, cand = tanh(pre_c + r * h_prev), h = (1 - z) h_prev + z cand  (:714-720);
+ *                     h -> h_out f32 [frames][OH*OW][64] AND out_img (the next step's convolution input); h_prev NULL = zeros
+ */
+enum { RAC_CD_IMAGE = 0, RAC_CD_F32 = 1, RAC_CD_GRU = 2 };
+typedef struct {
+    const float *amax;     /* device word or NULL */
+    float mul, add;
+} rac_cd_scale;
+typedef struct {
+    int live, stride, first;
+} rac_cd_frames;
+typedef struct {
+    int mode, conv_stride;           /* RAC_CD_*, 1 | 2 */
+    int N, H, W;                     /* frames processed; INPUT map size (output = H / conv_stride x W / conv_stride) */
+    const void *in_img;
+    int in_chunks_total, in_chunk0, chunks;
+    rac_cd_frames in_frames;
+    rac_cd_scale in_scale;
+    const void *ws;
+    float w_alpha;
+    int Cout;
+    const float *bias;               /* [Cout] or NULL (IMAGE, F32) */
+    void *out_img;                   /* IMAGE, GRU */
+    int out_chunks_total, out_chunk0;
+    rac_cd_frames out_frames;
+    rac_cd_scale out_scale;
+    float *out_f32;                  /* F32 */
+    const float *pixel_map;          /* F32: [OH*OW][Cout] or NULL */
+    const float *xpart;              /* GRU: [frames][OH*OW][192] */
+    rac_cd_frames xpart_frames;
+    const float *h_prev;             /* GRU: [frames][OH*OW][64] or NULL */
+    rac_cd_frames h_prev_frames;
+    float *h_out;                    /* GRU */
+    rac_cd_frames h_out_frames;
+} rac_conv_direct;
+int rac_conv_direct_fwd(const rac_conv_direct *desc, void *stream);
+
+/* nn.Upsample(scale_factor=2, bilinear, align_corners=True) (models/racformer_transformer.py:633-636) of channel-last maps
+ * src f32 [frames][h*w][C] straight into an activation image f16 [frames][2h+2][2w+2][C/32][hi 32 | lo 32] (interior pixels)
+ * with the scale act_scale(bound); C % 32 == 0. */
+int rac_upsample2x_image_fwd(const float *src, void *img, int frames, int h, int w, int C, float bound, void *stream);
+
+/* rac_conv3x3_fwd / rac_conv3x3_q16_fwd for a stack of [groups][frames_per_group] images of which only the first live_per_group
+ * of a group carry all Cin channels: the others' last Cin - Cin_dead channels are a per-channel constant (the ConvGRU leaves
+ * frames >= 4 at zero, so their hidden half is the bias of the convolution behind the resize, :674-693), whose contribution
+ * the caller has folded into THEIR per-pixel map (border-aware: composed through the zero padding) -- those images run
+ * Cin_dead / 32 chunks per tap and add pixel_bias_dead instead of pixel_bias_live.  Exactly one of out / (q, scale). */
+int rac_conv3x3_temporal_fwd(const void *xs, const void *ws, const float *pixel_bias_live, const float *pixel_bias_dead,
+                             const float *amax, float w_alpha, float *out, void *q, float *scale, int N, int H, int W, int Cin,
+                             int Cin_dead, int frames_per_group, int live_per_group, void *stream);
 
 #ifdef __cplusplus
 }

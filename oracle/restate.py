@@ -110,8 +110,8 @@ def _clib():
         if not os.path.exists(path):
             return None
         lib = ctypes.CDLL(path)
-        lib.oracle_msmv_fwd.restype = ctypes.c_int
-        lib.oracle_msda_fwd.restype = ctypes.c_int
+        for fn in ("oracle_msmv_fwd", "oracle_msda_fwd", "oracle_msmv_fwd_f64", "oracle_msda_fwd_f64"):
+            getattr(lib, fn).restype = ctypes.c_int
         _CLIB = lib
     return _CLIB
 
@@ -176,16 +176,20 @@ def msmv_gather(feats_cl, loc, w, force_torch=False):
     lib = None if force_torch else _clib()
     if lib is None:
         return msmv_gather_torch(feats_cl, loc, w)
-    feats_cl = [f.contiguous().float() for f in feats_cl]
-    loc, w = loc.contiguous().float(), w.contiguous().float()
+    # float32: the checker (the reference's arithmetic type).  float64 operands select the `_f64` instance of the same C text:
+    # the arbiter of tools/fp64_arbiter.py.
+    dt = torch.float64 if feats_cl[0].dtype == torch.float64 else torch.float32
+    feats_cl = [f.contiguous().to(dt) for f in feats_cl]
+    loc, w = loc.contiguous().to(dt), w.contiguous().to(dt)
     S, N = feats_cl[0].shape[:2]
     C = feats_cl[0].shape[-1]
     _, Q, P, _ = loc.shape
     L = len(feats_cl)
-    out = torch.empty(S, Q, C, P)
+    out = torch.empty(S, Q, C, P, dtype=dt)
     ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats_cl])
     hw = (ctypes.c_int32 * (2 * L))(*[int(x) for f in feats_cl for x in f.shape[2:4]])
-    rc = lib.oracle_msmv_fwd(ptrs, hw, L, ctypes.c_void_p(loc.data_ptr()),
+    fn = lib.oracle_msmv_fwd_f64 if dt == torch.float64 else lib.oracle_msmv_fwd
+    rc = fn(ptrs, hw, L, ctypes.c_void_p(loc.data_ptr()),
                              ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                              S, N, Q, P, C)
     assert rc == 0
@@ -219,13 +223,15 @@ def msda(value, shapes, starts, loc, attn, force_torch=False):
     lib = None if force_torch else _clib()
     if lib is None:
         return msda_torch(value, shapes, starts, loc, attn)
-    value, loc, attn = value.contiguous().float(), loc.contiguous().float(), attn.contiguous().float()
+    dt = torch.float64 if value.dtype == torch.float64 else torch.float32
+    value, loc, attn = value.contiguous().to(dt), loc.contiguous().to(dt), attn.contiguous().to(dt)
     shapes = torch.as_tensor(shapes, dtype=torch.int64).contiguous()
     starts = torch.as_tensor(starts, dtype=torch.int64).contiguous()
     bs, keys, heads, dim = value.shape
     _, Q, _, L, P, _ = loc.shape
-    out = torch.empty(bs, Q, heads * dim)
-    rc = lib.oracle_msda_fwd(ctypes.c_void_p(value.data_ptr()), ctypes.c_void_p(shapes.data_ptr()),
+    out = torch.empty(bs, Q, heads * dim, dtype=dt)
+    fn = lib.oracle_msda_fwd_f64 if dt == torch.float64 else lib.oracle_msda_fwd
+    rc = fn(ctypes.c_void_p(value.data_ptr()), ctypes.c_void_p(shapes.data_ptr()),
                              ctypes.c_void_p(starts.data_ptr()), ctypes.c_void_p(loc.data_ptr()),
                              ctypes.c_void_p(attn.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                              bs, keys, heads, dim, Q, L, P)

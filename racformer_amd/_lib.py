@@ -60,6 +60,9 @@ SIGNATURES = {
     "rac_bev_sampling_multi_fwd": (_i, [_i] + [_vp] * 9 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _i, _vp]),
     "rac_bev_sampling_multi_q16_fwd": (_i, [_i] + [_vp] * 10 + [_i] * 4 + [_i] * 9 + [_vp, _vp, _f, _vp]),
     "rac_quant_i16_fwd": (_i, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
+    "rac_conv_direct_fwd": (_i, [_vp, _vp]),
+    "rac_upsample2x_image_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "rac_conv3x3_temporal_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
 }
 
 
@@ -75,6 +78,29 @@ class RowGemm(ctypes.Structure):
     """rac_rowgemm (include/racformer_hip.h)"""
     _fields_ = [("seg", RowSeg * 3), ("w", _vp), ("b", _vp), ("out", _vp), ("num_seg", _i), ("N", _i), ("ld_out", _i),
                 ("relu_from", _i)]
+
+
+class CdScale(ctypes.Structure):
+    """rac_cd_scale (include/racformer_hip.h)"""
+    _fields_ = [("amax", _vp), ("mul", _f), ("add", _f)]
+
+
+class CdFrames(ctypes.Structure):
+    """rac_cd_frames (include/racformer_hip.h)"""
+    _fields_ = [("live", _i), ("stride", _i), ("first", _i)]
+
+
+class ConvDirect(ctypes.Structure):
+    """rac_conv_direct (include/racformer_hip.h)"""
+    _fields_ = [("mode", _i), ("conv_stride", _i), ("N", _i), ("H", _i), ("W", _i), ("in_img", _vp), ("in_chunks_total", _i),
+                ("in_chunk0", _i), ("chunks", _i), ("in_frames", CdFrames), ("in_scale", CdScale), ("ws", _vp), ("w_alpha", _f),
+                ("Cout", _i), ("bias", _vp), ("out_img", _vp), ("out_chunks_total", _i), ("out_chunk0", _i),
+                ("out_frames", CdFrames), ("out_scale", CdScale), ("out_f32", _vp), ("pixel_map", _vp), ("xpart", _vp),
+                ("xpart_frames", CdFrames), ("h_prev", _vp), ("h_prev_frames", CdFrames), ("h_out", _vp),
+                ("h_out_frames", CdFrames)]
+
+
+CD_IMAGE, CD_F32, CD_GRU = 0, 1, 2
 
 
 def lib():

@@ -35,14 +35,8 @@ typedef float cv_f4 __attribute__((ext_vector_type(4)));
 #define CV_COUT 256
 #define CV_STAGE_U4 4096 /* uint4 per LDS stage: A 2048 + B 2048 */
 
-// power of two that brings amax into [2^13, 2^14) (1 for amax == 0 or non-finite input)
-__device__ __forceinline__ float cv_act_scale(float amax)
-{
-    if (!(amax > 1.0e-30f) || !(amax < 3.0e38f))
-        return 1.f;
-    const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 126;   // amax = m * 2^ex, m in [0.5, 1)
-    return __uint_as_float((unsigned)(14 - ex + 127) << 23);             // 2^(14 - ex)
-}
+// power of two that brings amax into [2^13, 2^14): rac_act_scale (rac_common.h; shared with conv_direct.hip)
+#define cv_act_scale rac_act_scale
 
 // ------------------------------------------------------------------------------------------------ absmax
 // (a one-thread launch rather than a memset: inside a captured HIP graph the step then consists of kernel nodes only, whose
@@ -167,6 +161,11 @@ struct ConvArgs {
     int cams;                 // GROUPED output only: images per (batch, frame)
     short *q;                 // Q16 output only: [N][H*W][256] int16 mantissas and
     float *qscale;            //   [N][H*W][4] one power-of-two scale per (pixel, 64-channel block); out is unused
+    // rac_conv3x3_temporal_fwd: images come in groups of `fpg` frames (0: no grouping) of which the first `live` carry all chunks; the
+    // others run only `chunks_dead` chunks per tap and add `pixel_bias_dead` -- their remaining channels are a per-channel constant
+    // whose contribution through the zero padding the caller folded into that map
+    const float *pixel_bias_dead;
+    int fpg, live, chunks_dead;
 };
 enum { CV_OUT_NHWC = 0, CV_OUT_GROUPED = 1, CV_OUT_Q16 = 2 };
 __device__ __forceinline__ cv_f4 cv_fma4(cv_f4 a, float s, cv_f4 b)
@@ -191,7 +190,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
     const int HW = H * W;
     const int tiles_per_img = (HW + CV_TM - 1) / CV_TM;    // the last tile of an image may be ragged: its rows past the image
     const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;   // re-read the last pixel and are not stored
-    const int KS = 9 * chunks;
+    // (round 5) frames past a group's live ones: fewer chunks per tap, another per-pixel map; the image and weight strides stay `chunks`
+    const bool dead = a.fpg > 0 && (n % a.fpg) >= a.live;
+    const int KS = 9 * (dead ? a.chunks_dead : chunks);
     const size_t pix_stride = (size_t)chunks * 8;   // uint4 per pixel
 
     // staging role: 16-byte slot (tid & 7) of rows (tid >> 3) + 64 j of both the A and the B tile
@@ -384,7 +385,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16x3_kernel(const ConvArgs a)
         }
         return;
     }
-    const float *pbase = a.pixel_bias ? a.pixel_bias + (size_t)tile * CV_TM * CV_COUT : nullptr;
+    const float *pmap = dead ? a.pixel_bias_dead : a.pixel_bias;
+    const float *pbase = pmap ? pmap + (size_t)tile * CV_TM * CV_COUT : nullptr;
     if (MODE == CV_OUT_Q16) {
         // A (pixel, 64-channel block) of the value stream is pixel li of tile m in wave column wn: its 64 values are the 16 this
         // lane holds (4 tiles nn x 4 registers) and those of the lanes li + 16, li + 32, li + 48 -- block maximum = 16 in-lane
@@ -634,7 +636,8 @@ extern "C" int rac_conv_pack_bias_fwd(const float *src, const float *bias, const
 }
 
 static int cv_launch_plain(const void *xs, const void *ws, const float *bias, const float *pixel_bias, const float *amax, float w_alpha,
-                           float *out, void *q, float *qscale, int N, int H, int W, int Cin, int Cout, void *stream, const char *what)
+                           float *out, void *q, float *qscale, int N, int H, int W, int Cin, int Cout, void *stream, const char *what,
+                           const float *pixel_bias_dead = nullptr, int Cin_dead = 0, int frames_per_group = 0, int live_per_group = 0)
 {
     RAC_CHECK_ARG(Cout == CV_COUT, "%s: built for %d output channels (got %d)", what, CV_COUT, Cout);
     RAC_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "%s: Cin=%d (multiple of 32)", what, Cin);
@@ -644,13 +647,15 @@ static int cv_launch_plain(const void *xs, const void *ws, const float *bias, co
         return 0;
     RAC_CHECK_ARG(xs && ws && amax && (out || (q && qscale)), "%s: null pointer", what);
     RAC_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pixel_bias) |
-                    reinterpret_cast<uintptr_t>(q)) & 15) == 0, "%s: out / bias / pixel_bias must be 16-byte aligned", what);
+                    reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(pixel_bias_dead)) & 15) == 0,
+                  "%s: out / bias / pixel_bias must be 16-byte aligned", what);
     ConvArgs a;
     a.xs = reinterpret_cast<const uint4 *>(xs);
     a.ws = reinterpret_cast<const uint4 *>(ws);
     a.bias = bias; a.pixel_bias = pixel_bias; a.amax = amax; a.out = out;
     a.q = reinterpret_cast<short *>(q); a.qscale = qscale;
     a.N = N; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = 1;
+    a.pixel_bias_dead = pixel_bias_dead; a.fpg = pixel_bias_dead ? frames_per_group : 0; a.live = live_per_group; a.chunks_dead = Cin_dead / 32;
     const int lds = 2 * CV_STAGE_U4 * 16;
     const dim3 grid((unsigned)(N * ((H * W + CV_TM - 1) / CV_TM)));
     if (q) {
@@ -678,6 +683,20 @@ extern "C" int rac_conv3x3_q16_fwd(const void *xs, const void *ws, const float *
     return cv_launch_plain(xs, ws, bias, pixel_bias, amax, w_alpha, nullptr, q, scale, N, H, W, Cin, Cout, stream, "rac_conv3x3_q16_fwd");
 }
 
+extern "C" int rac_conv3x3_temporal_fwd(const void *xs, const void *ws, const float *pixel_bias_live, const float *pixel_bias_dead,
+                                        const float *amax, float w_alpha, float *out, void *q, float *scale, int N, int H, int W, int Cin,
+                                        int Cin_dead, int frames_per_group, int live_per_group, void *stream)
+{
+    const char *what = "rac_conv3x3_temporal_fwd";
+    RAC_CHECK_ARG(frames_per_group >= 1 && live_per_group >= 0 && live_per_group <= frames_per_group && N % frames_per_group == 0,
+                  "%s: N=%d images in groups of %d, %d live", what, N, frames_per_group, live_per_group);
+    RAC_CHECK_ARG(Cin_dead > 0 && Cin_dead % 32 == 0 && Cin_dead <= Cin, "%s: Cin_dead=%d (a multiple of 32, <= Cin=%d)", what, Cin_dead, Cin);
+    RAC_CHECK_ARG(N == 0 || (pixel_bias_live && pixel_bias_dead), "%s: both per-pixel maps are needed", what);
+    RAC_CHECK_ARG((out != nullptr) != (q != nullptr && scale != nullptr), "%s: exactly one of out / (q, scale)", what);
+    return cv_launch_plain(xs, ws, nullptr, pixel_bias_live, amax, w_alpha, out, q, scale, N, H, W, Cin, CV_COUT, stream, what, pixel_bias_dead,
+                           Cin_dead, frames_per_group, live_per_group);
+}
+
 extern "C" int rac_fpn_conv_fwd(const void *xs, const void *ws, const float *bias, const float *amax, float w_alpha, float *out,
                                 int num_images, int H, int W, int Cin, int num_cams, void *stream)
 {
@@ -695,6 +714,7 @@ extern "C" int rac_fpn_conv_fwd(const void *xs, const void *ws, const float *bia
     a.ws = reinterpret_cast<const uint4 *>(ws);
     a.bias = bias; a.pixel_bias = nullptr; a.amax = amax; a.out = out;
     a.N = num_images; a.H = H; a.W = W; a.chunks = Cin / 32; a.w_alpha = w_alpha; a.cams = num_cams; a.q = nullptr; a.qscale = nullptr;
+    a.pixel_bias_dead = nullptr; a.fpg = 0; a.live = 0; a.chunks_dead = 0;
     const int lds = 2 * CV_STAGE_U4 * 16;
     if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_FPN_CONV, reinterpret_cast<const void *>(conv3x3_f16x3_kernel<CV_OUT_GROUPED>), (int)(lds)))
         return rc_attr;

@@ -13,7 +13,23 @@ void rac_set_error(const char *fmt, ...);
 // limit) on the CURRENT device unless an earlier call already did, from any thread; 0 or the HIP error (rac_last_error set).  (capi.cpp)
 int rac_set_dynamic_lds_once(int id, const void *func, int bytes);
 enum { RAC_ATTR_GEMM_SPLIT = 0, RAC_ATTR_GENERATOR, RAC_ATTR_CONV3X3, RAC_ATTR_CONV3X3S2, RAC_ATTR_MIXING_F32, RAC_ATTR_MIXING_F16,
-       RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV, RAC_ATTR_GENERATOR4, RAC_ATTR_CONV3X3_Q16, RAC_ATTR_VALUE_PROJ_Q16, RAC_ATTR_MIXING_SAMPLED };
+       RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV, RAC_ATTR_GENERATOR4, RAC_ATTR_CONV3X3_Q16, RAC_ATTR_VALUE_PROJ_Q16, RAC_ATTR_MIXING_SAMPLED,
+       RAC_ATTR_CD_GRU, RAC_ATTR_CD_S2_8, RAC_ATTR_CD_S2_2, RAC_ATTR_CD_S2_3, RAC_ATTR_CD_IMG_2, RAC_ATTR_CD_F32_1, RAC_ATTR_CD_F32_2,
+       RAC_ATTR_CD_F32_4 };
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (straight-line code with the index usable in constexpr contexts)
+template <int I>
+struct rac_ic {
+    static constexpr int value = I;
+};
+template <int B, int E, typename F>
+__device__ __forceinline__ void rac_static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(rac_ic<B>{});
+        rac_static_for<B + 1, E>(f);
+    }
+}
 
 #define RAC_CHECK_ARG(cond, ...)            \
     do {                                    \
@@ -86,7 +102,7 @@ __device__ __forceinline__ rac_f4 rac_ld4(const unsigned short *p)
 // Four channels of one bilinear tap into a lane's running sums (the gather kernels' inner operation).
 // Scalar v_fma_f32, deliberately NOT v_pk_fma_f32 (two channels per instruction, what round 2 used): beside another stream's
 // MFMA kernels (mixing_c64_f16x3_kernel, conv3x3_f16x3_kernel -- several samples in flight, racformer_amd/graph.py) the packed
-// form produced wrong sums in 4-lane granules in every gather kernel while the scalar form never did (tools/dbg_race*.py:
+// form produced wrong sums in 4-lane granules in every gather kernel while the scalar form never did (round 3; tools/race_victims.py is the tool that remains:
 // rac_msmv_fwd beside a looping mixing kernel, 110 of 120 launches deviating with v_pk_fma_f32, 0 of 120 with v_fma_f32; same
 // loads, same waits, plain global loads instead of buffer loads made no difference).  Same rounding either way (IEEE fma per
 // component), so results are bit-identical to round 2's.
@@ -146,6 +162,17 @@ __device__ __forceinline__ void rac_split_f16(float v, _Float16 &hi, _Float16 &l
 {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
+}
+
+// The activations' power-of-two scale of the split-precision convolution kernels (conv3x3.hip, conv_direct.hip): brings amax -- the
+// maximum |value| of an activation image, or a bound of it -- into [2^13, 2^14) (1 for amax == 0 or non-finite input), so that hi is a
+// normal f16 for every value and lo keeps the next 11 bits down to values 2^-13 of the maximum.
+__device__ __forceinline__ float rac_act_scale(float amax)
+{
+    if (!(amax > 1.0e-30f) || !(amax < 3.0e38f))
+        return 1.f;
+    const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 126;   // amax = m * 2^ex, m in [0.5, 1)
+    return __uint_as_float((unsigned)(14 - ex + 127) << 23);             // 2^(14 - ex)
 }
 
 // int16 block storage of a BEV value stream (quant.hip; the q16 epilogues of conv3x3.hip and value_proj.hip): value = q * dn with

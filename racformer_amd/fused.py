@@ -609,6 +609,32 @@ class ConvImage:
         _lib.check(rc, what)
         return (out, scale) if q16 else out
 
+    def conv_temporal(self, ws, w_alpha, pixel_bias_live, pixel_bias_dead, cin_dead, frames_per_group, live_per_group, q16=False):
+        """``conv`` for a stack of [groups, frames_per_group] images whose frames past the first ``live_per_group`` of a group carry a
+        per-channel CONSTANT in the channels from ``cin_dead`` on: those images multiply only their first ``cin_dead`` channels and add
+        ``pixel_bias_dead`` (the constant's contribution through the zero padding, folded in by the caller) instead of
+        ``pixel_bias_live`` (rac_conv3x3_temporal_fwd).  Same outputs as ``conv``."""
+        N, H, W = self.N, self.H, self.W
+        for pb in (pixel_bias_live, pixel_bias_dead):
+            if tuple(pb.shape) != (H * W, 256) or not pb.is_contiguous() or pb.dtype != torch.float32 or not pb.is_cuda:
+                raise RuntimeError("ConvImage.conv_temporal: the per-pixel maps must be contiguous float32 CUDA [H*W, 256] tensors")
+        if q16:
+            out = torch.empty(N, H * W, 4, 64, device=self.dev, dtype=torch.int16)
+            scale = torch.empty(N, H * W, 4, device=self.dev, dtype=torch.float32)
+        else:
+            out, scale = torch.empty(N, H, W, 256, device=self.dev, dtype=torch.float32), None
+        ev = _lib.timer.record("temporal_fusion_conv") if _lib.timer is not None else None
+        if ev:
+            ev[0].record()
+        rc = _lib.lib().rac_conv3x3_temporal_fwd(_lib.ptr(self.xs), _lib.ptr(ws), _lib.ptr(pixel_bias_live), _lib.ptr(pixel_bias_dead),
+                                                 _lib.ptr(self.amax), float(w_alpha), None if q16 else _lib.ptr(out),
+                                                 _lib.ptr(out) if q16 else None, _lib.ptr(scale) if q16 else None, N, H, W, self.cin,
+                                                 int(cin_dead), int(frames_per_group), int(live_per_group), _lib.stream_ptr())
+        if ev:
+            ev[1].record()
+        _lib.check(rc, "rac_conv3x3_temporal_fwd")
+        return (out, scale) if q16 else out
+
     def conv_s2(self, ws, w_alpha, bias, cin, out=None):
         """3x3 / stride 2 / pad 1 convolution of the image's first ``cin`` channels -> [N, 64, H/2, W/2] fp32 (NCHW), or
         into channels 0..63 of a given contiguous ``out`` [N, Ctot, H/2, W/2]."""
@@ -639,6 +665,64 @@ def conv3x3_fused(sources, ws, w_alpha, bias, bounds=None, pixel_bias=None):
         img.pack(t, off)
         off += int(t.shape[1])
     return img.conv(ws, w_alpha, bias, pixel_bias)
+
+
+# ------------------------------------------------------------------------------------------- ConvGRU branch, own kernels (round 5)
+def act_image(tag, frames, H, W, channels, device):
+    """A zero-bordered activation image f16 [frames, H+2, W+2, channels/32, 2, 32] of the convolution kernels, from the reusable
+    scratch of the current namespace (scratch_namespace): allocated zeroed once per (tag, shape); its producers write interior
+    pixels only, so the border stays the convolutions' zero padding."""
+    key = ("act", tag, frames, H, W, channels, str(device), _scratch_ns[0])
+    img = _conv_images.get(key)
+    if img is None:
+        img = _conv_images[key] = torch.zeros(frames, H + 2, W + 2, channels // 32, 2, 32, device=device, dtype=torch.float16)
+    return img
+
+
+def _cd_scale(amax=None, mul=0.0, add=0.0):
+    return _lib.CdScale(_lib.ptr(amax) if amax is not None else None, float(mul), float(add))
+
+
+def _cd_frames(live=1, stride=1, first=0):
+    return _lib.CdFrames(int(live), int(stride), int(first))
+
+
+def conv_direct(mode, N, H, W, in_img, in_chunks_total, chunks, ws, w_alpha, cout, in_scale, conv_stride=1, in_chunk0=0,
+                in_frames=None, bias=None, out_img=None, out_chunks_total=0, out_chunk0=0, out_frames=None, out_scale=None,
+                out_f32=None, pixel_map=None, xpart=None, xpart_frames=None, h_prev=None, h_prev_frames=None, h_out=None,
+                h_out_frames=None):
+    """rac_conv_direct_fwd (include/racformer_hip.h): 3x3 convolution of a small activation image without LDS staging, epilogue
+    ``mode`` = _lib.CD_IMAGE (another activation image) / CD_F32 (channel-last fp32 + per-pixel map) / CD_GRU (the ConvGRU update).
+    Scales are (amax tensor | None, mul, add) triples, frame maps (live, stride, first) triples."""
+    opt = lambda t: _lib.ptr(t) if t is not None else None      # noqa: E731
+    fr = lambda f: _cd_frames(*(f or (1, 1, 0)))                # noqa: E731
+    d = _lib.ConvDirect()
+    d.mode, d.conv_stride, d.N, d.H, d.W = int(mode), int(conv_stride), int(N), int(H), int(W)
+    d.in_img, d.in_chunks_total, d.in_chunk0, d.chunks = opt(in_img), int(in_chunks_total), int(in_chunk0), int(chunks)
+    d.in_frames, d.in_scale = fr(in_frames), _cd_scale(*in_scale)
+    d.ws, d.w_alpha, d.Cout, d.bias = opt(ws), float(w_alpha), int(cout), opt(bias)
+    d.out_img, d.out_chunks_total, d.out_chunk0 = opt(out_img), int(out_chunks_total), int(out_chunk0)
+    d.out_frames, d.out_scale = fr(out_frames), _cd_scale(*(out_scale or (None, 0.0, 0.0)))
+    d.out_f32, d.pixel_map = opt(out_f32), opt(pixel_map)
+    d.xpart, d.xpart_frames = opt(xpart), fr(xpart_frames)
+    d.h_prev, d.h_prev_frames = opt(h_prev), fr(h_prev_frames)
+    d.h_out, d.h_out_frames = opt(h_out), fr(h_out_frames)
+    for t in (in_img, ws, bias, out_img, out_f32, pixel_map, xpart, h_prev, h_out):
+        if t is not None:
+            _lib.require_gpu(t, what="conv_direct")
+    _lib.check(_lib.lib().rac_conv_direct_fwd(ctypes.byref(d), _lib.stream_ptr()), "rac_conv_direct_fwd")
+
+
+def upsample2x_image(src, img, bound):
+    """nn.Upsample(x2, bilinear, align_corners=True) of channel-last maps ``src`` f32 [frames, h*w, C] (given as [frames, h, w, C])
+    into the activation image ``img`` [frames, 2h+2, 2w+2, C/32, 2, 32] with the scale of ``bound`` (rac_upsample2x_image_fwd)."""
+    _lib.require_gpu(src, img, what="upsample2x_image")
+    frames, h, w, C = src.shape
+    if tuple(img.shape) != (frames, 2 * h + 2, 2 * w + 2, C // 32, 2, 32) or img.dtype != torch.float16 or src.dtype != torch.float32:
+        raise RuntimeError("upsample2x_image: src f32 [frames,h,w,C], img f16 [frames,2h+2,2w+2,C/32,2,32] expected")
+    _lib.check(_lib.lib().rac_upsample2x_image_fwd(_lib.ptr(src), _lib.ptr(img), frames, h, w, C, float(bound), _lib.stream_ptr()),
+               "rac_upsample2x_image_fwd")
+    return img
 
 
 # ------------------------------------------------------------------------------------------- temporal encoder pieces

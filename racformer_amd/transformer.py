@@ -26,8 +26,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
-from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, add_ln, bev_sampling_fused, bev_sampling_multi_fused, box_prep,
-                    quantize_values_i16,
+from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, act_image, add_ln, bev_sampling_fused, bev_sampling_multi_fused,
+                    box_prep, conv_direct, quantize_values_i16, upsample2x_image,
                     generator_fused, gru_gate_fused, layer_boundary_fused, mixing_fused, mixing_sampled_fused, mixing_sampled_supported, outproj_fused,
                     pack_conv3x3_weight,
                     pack_gemm_split_weight,
@@ -400,6 +400,17 @@ def convgru_fused_pack(gru, h, w):
     return wp.to(dev), bmap.to(dev)
 
 
+def dead_frame_bias_map(w_hidden, b_hidden, H, W):
+    """Contribution of a per-channel CONSTANT input b_hidden [Ch] through a 3x3 / pad 1 convolution with weights w_hidden
+    [Cout, Ch, 3, 3] (float64): [H*W, Cout] -- the same everywhere except at the border, where the zero padding cuts taps off.
+    What the frames past the ConvGRU's live ones contribute to the temporal-fusion convolution through their hidden half
+    (racformer_transformer.py:674-693: those frames of the ConvGRU output are zero, so their hidden half is the bias of the
+    convolution behind the resize)."""
+    ch = w_hidden.shape[1]
+    const = b_hidden.double().view(1, ch, 1, 1).expand(1, ch, H, W).contiguous()
+    return F.conv2d(const, w_hidden.double(), None, padding=1)[0].reshape(w_hidden.shape[0], H * W).t().contiguous()
+
+
 class RadarBEVTemporalEncoder(nn.Module):
     """racformer_transformer.py:618-663"""
 
@@ -472,7 +483,32 @@ class RadarBEVTemporalEncoder(nn.Module):
             gw, gmap = convgru_fused_pack(self.convGRU, H // 2, W // 2)
             if gw is not None:
                 pack.update(gru_w=gw, gru_bmap=gmap)
+                # round 5, the branch on own kernels (rac_conv_direct_fwd): the gates convolution split into its x half (all live
+                # frames in one launch, the bias map in its epilogue, channel-last) and its h half (the recurrence), the convolution
+                # behind the resize, and the bound of |downsample(x)| per unit of max|x| that gives the downsampled image its scale
+                up = self.upsample[1]
+                hd = self.hidden_dims
+                gx, gx_a = pack_conv3x3_weight(gw[:, :hd].contiguous(), cout=3 * hd)
+                gh, gh_a = pack_conv3x3_weight(gw[:, hd:].contiguous(), cout=3 * hd)
+                uw, uw_a = pack_conv3x3_weight(up.weight, cout=hd) if up.kernel_size == (3, 3) and up.padding == (1, 1) else (None, None)
+                if gx is not None and gh is not None and uw is not None and hd == 64:
+                    pack.update(gx_ws=gx, gx_alpha=gx_a, gh_ws=gh, gh_alpha=gh_a, up_ws=uw, up_alpha=uw_a,
+                                gru_bmap_cl=gmap.reshape(3 * hd, -1).t().contiguous(),
+                                down_l1=float(d.weight.detach().abs().sum(dim=(1, 2, 3)).max()),
+                                down_bmax=float(d.bias.detach().abs().max()) if d.bias is not None else 0.0)
         return pack
+
+    def temporal_bias_maps(self, H, W):
+        """The per-pixel maps of rac_conv3x3_temporal_fwd for the UN-composed convolution: the bias for the live frames, the bias
+        plus the constant hidden half's contribution for the frames past them ({} for shapes the kernel's map does not tile)."""
+        tf, up = self.temporal_fusion, self.upsample[1]
+        if (H * W) % 256 != 0 or tf.weight.shape[0] != 256:
+            return {}
+        b = tf.bias.detach().double() if tf.bias is not None else tf.weight.new_zeros(tf.weight.shape[0]).double()
+        b_up = up.bias.detach().double() if up.bias is not None else b.new_zeros(self.hidden_dims)
+        live = b.view(1, -1).expand(H * W, -1)
+        dead = live + dead_frame_bias_map(tf.weight.detach().double()[:, self.embed_dims:], b_up, H, W).to(b.device)
+        return dict(pixel_bias=live.float().contiguous(), pixel_bias_dead=dead.float().contiguous(), composed=False)
 
     def hidden_bound(self):
         """Upper bound of |hidden_stream(.)[1]| from the weights of the last convolution (inputs bounded by 1)."""
@@ -503,6 +539,10 @@ class RadarBEVTemporalEncoder(nn.Module):
             x = bev_feats.flatten(0, 1).contiguous()
             img.begin([x], packed["bound"]).pack(x, 0)
             hd, Tv = self.hidden_dims, min(4, T)
+            if (packed.get("gx_ws") is not None and packed.get("pixel_bias_dead") is not None and self.downsample_ratio == 2
+                    and hd == 64 and C % 32 == 0 and H % 2 == 0 and W % 2 == 0
+                    and tuple(packed["gru_bmap_cl"].shape) == ((H // 2) * (W // 2), 3 * hd)):
+                return self._forward_own_gru(img, packed, B, T, Tv, C, H, W, q16)
             own_down = packed.get("down_ws") is not None and self.downsample_ratio == 2 and ((H // 2) * (W // 2)) % 128 == 0
             if own_down and packed.get("gru_w") is not None and Tv < T and tuple(packed["gru_bmap"].shape[1:]) == (H // 2, W // 2):
                 # launch-lean ConvGRU: the downsample kernel writes the x half of every step's convolution input
@@ -533,6 +573,41 @@ class RadarBEVTemporalEncoder(nn.Module):
                 hid = self.hidden_from_down(down, H, W)
         img.pack(hid.contiguous(), C)
         return img.conv(packed["ws"], packed["alpha"], None if pb is not None else self.temporal_fusion.bias, pb, q16=q16)
+
+
+    def _forward_own_gru(self, img, packed, B, T, Tv, C, H, W, q16):
+        """Round 5: the whole ConvGRU branch on rac_conv_direct_fwd launches (no library convolution, no LDS staging: the maps are
+        64 x 64 and the chain is sequential), every intermediate an activation image whose power-of-two scale follows
+        from the weights (|h| <= 1; |downsample(x)| <= ||W||_1 max|x| + max|b|) -- the x half of ``img`` has been packed by the caller:
+          downsample (stride 2) of the Tv live frames -> image;  gates convolution's x half for the Tv frames + bias map -> xpart;
+          Tv recurrence launches (h half of the gates convolution + the GRU update in the epilogue; step 0 has h = 0: no K loop);
+          2x bilinear resize -> image;  64 -> 64 convolution + bias -> the hidden chunks of the live frames of ``img``;
+          temporal-fusion convolution: live frames all 10 chunks, the others 8 chunks + their own per-pixel map (their hidden half is
+          the constant b_up)."""
+        dev, hd = img.xs.device, self.hidden_dims
+        h, w, cx = H // 2, W // 2, C // 32
+        live = B * Tv
+        fus = (img.amax, 1.0, 0.0)                                         # the fusion image's scale: its measured maximum
+        dsc = (img.amax, packed["down_l1"], packed["down_bmax"])          # |downsample(x)| <= l1 * max|x| + max|b|
+        one = (None, 0.0, 1.0)                                            # |ConvGRU state| <= 1 (and its bilinear resize)
+        down_img, h_img = act_image("gru_down", live, h, w, hd, dev), act_image("gru_h", live, h, w, hd, dev)
+        up_img = act_image("gru_up", live, H, W, hd, dev)
+        conv_direct(_lib.CD_IMAGE, live, H, W, img.xs, img.cin // 32, cx, packed["down_ws"], packed["down_alpha"], hd, fus, conv_stride=2,
+                    in_frames=(Tv, T, 0), bias=self.downsample.bias, out_img=down_img, out_chunks_total=hd // 32, out_scale=dsc)
+        xpart = torch.empty(live, h * w, 3 * hd, device=dev, dtype=torch.float32)
+        conv_direct(_lib.CD_F32, live, h, w, down_img, hd // 32, hd // 32, packed["gx_ws"], packed["gx_alpha"], 3 * hd, dsc,
+                    out_f32=xpart, pixel_map=packed["gru_bmap_cl"])
+        hs = torch.empty(live, h, w, hd, device=dev, dtype=torch.float32)
+        for t in range(Tv):
+            conv_direct(_lib.CD_GRU, B, h, w, h_img, hd // 32, 0 if t == 0 else hd // 32, packed["gh_ws"], packed["gh_alpha"], 3 * hd, one,
+                        in_frames=(1, Tv, max(t - 1, 0)), out_img=h_img, out_chunks_total=hd // 32, out_frames=(1, Tv, t), out_scale=one,
+                        xpart=xpart, xpart_frames=(1, Tv, t), h_prev=hs if t > 0 else None, h_prev_frames=(1, Tv, max(t - 1, 0)),
+                        h_out=hs, h_out_frames=(1, Tv, t))
+        upsample2x_image(hs, up_img, 1.0)
+        conv_up = self.upsample[1]
+        conv_direct(_lib.CD_IMAGE, live, H, W, up_img, hd // 32, hd // 32, packed["up_ws"], packed["up_alpha"], hd, one,
+                    bias=conv_up.bias, out_img=img.xs, out_chunks_total=img.cin // 32, out_chunk0=cx, out_frames=(Tv, T, 0), out_scale=fus)
+        return img.conv_temporal(packed["ws"], packed["alpha"], packed["pixel_bias"], packed["pixel_bias_dead"], C, T, Tv, q16=q16)
 
 
 class BEVSelfAttention(nn.Module):
@@ -647,7 +722,7 @@ class BEVSampling(nn.Module):
         if self.temp_radar and conv_pack is not None and conv_pack.get("ws") is not None and \
                 self.temporal_encoder.fused_conv_supported(bev_feats):
             B, T = bev_feats.shape[:2]
-            composed = conv_pack.get("pixel_bias") is not None
+            composed = bool(conv_pack.get("composed"))
             nhwc = self.temporal_encoder.forward_channel_last(bev_feats, conv_pack, q16=q16 and composed and self.attention.num_heads == 4)
             if isinstance(nhwc, tuple):
                 return nhwc, (H, W)
@@ -674,8 +749,15 @@ class BEVSampling(nn.Module):
         if ws is None:
             return {}
         pos = self.positional_encoding.grid(H, W).detach().double().reshape(-1, H * W)            # [C, HW]
-        pixel_bias = (pos.t() @ wv.t() + (wv @ bc + bv)).float().contiguous()                          # [HW, C]
-        return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), pixel_bias=pixel_bias, **te.downsample_pack(H, W))
+        pixel_bias = pos.t() @ wv.t() + (wv @ bc + bv)                                                # [HW, C]
+        # frames past the ConvGRU's live ones: their hidden half is the constant b_up; its contribution goes into THEIR map and
+        # the kernel skips those two chunks for them (rac_conv3x3_temporal_fwd)
+        up = te.upsample[1]
+        b_up = up.bias.detach().double() if up.bias is not None else wv.new_zeros(te.hidden_dims)
+        w_comp = torch.einsum("oc,cikl->oikl", wv, wc)
+        dead = pixel_bias + dead_frame_bias_map(w_comp[:, te.embed_dims:], b_up, H, W).to(pixel_bias.device)
+        return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), pixel_bias=pixel_bias.float().contiguous(),
+                    pixel_bias_dead=dead.float().contiguous(), composed=True, **te.downsample_pack(H, W))
 
     def keypoints(self, query_ray, query_feat, time_diff, d_region):
         """-> loc [B,Q,heads,T,P,2] in [0,1], weights [B,Q,heads,T,1,P] (:490-529)."""
@@ -1033,7 +1115,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             cell = te.convGRU.convGRUCell
             conv_params = [te.temporal_fusion.weight, up.weight, te.downsample.weight, cell.gates_conv.weight,
                            cell.matching_layer.weight] + \
-                [m.bias for m in (te.temporal_fusion, up, cell.gates_conv, cell.matching_layer) if m.bias is not None]
+                [m.bias for m in (te.temporal_fusion, up, cell.gates_conv, cell.matching_layer, te.downsample) if m.bias is not None]
             if self.compose_radar_value:
                 pe_, vp = rbs.positional_encoding, rbs.attention.value_proj
                 conv_pack = self._cached(f"conv_value_pack_{Hr}x{Wr}", conv_params + [vp.weight, vp.bias, pe_.row_embed.weight,
@@ -1042,7 +1124,7 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             if not conv_pack:
                 def plain_pack():
                     ws, alpha = pack_conv3x3_weight(te.temporal_fusion.weight)
-                    return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), **te.downsample_pack(Hr, Wr))
+                    return dict(ws=ws, alpha=alpha, bound=te.hidden_bound(), **te.temporal_bias_maps(Hr, Wr), **te.downsample_pack(Hr, Wr))
                 conv_pack = self._cached(f"conv_pack_{Hr}x{Wr}", conv_params, plain_pack)
         lbs = self.sampling_lss_bev
         if lss_bev_feats.is_cuda and self.fused:

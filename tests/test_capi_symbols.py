@@ -12,6 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "racformer_amd", "csrc", "libracformer_hip.so")
 
 
+def header_abi_version():
+    text = open(os.path.join(ROOT, "include", "racformer_hip.h")).read()
+    return int(re.search(r"#define\s+RAC_ABI_VERSION\s+(\d+)", text).group(1))
+
+
 def declared_symbols():
     names = []
     for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
@@ -39,7 +44,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for s in declared_symbols():
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
     lib.rac_abi_version.restype = ctypes.c_int
-    assert lib.rac_abi_version() == 7
+    assert lib.rac_abi_version() == header_abi_version() >= 8
 
 
 def declared_params():
@@ -58,7 +63,7 @@ def declared_params():
 def test_python_binding_covers_header(built_lib):
     from racformer_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib().rac_abi_version() == 7
+    assert _lib.lib().rac_abi_version() == header_abi_version()
     kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f", ctypes.c_int64: "l"}
     for name, kinds in declared_params().items():
         got = [kind[a] for a in _lib.SIGNATURES[name][1]]

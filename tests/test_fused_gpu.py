@@ -504,7 +504,13 @@ def test_temporal_encoder_fused_pieces():
         eg = enc.to(DEV)
         ws, alpha = pack_conv3x3_weight(eg.temporal_fusion.weight)
         got = eg.forward_channel_last(bev.to(DEV), dict(ws=ws, alpha=alpha, bound=eg.hidden_bound(), **eg.downsample_pack(16, 16)))
+        # round 5: with the per-pixel maps in the pack the ConvGRU branch runs on rac_conv_direct_fwd and the fusion convolution
+        # skips the constant hidden half of the frames past the live ones (rac_conv3x3_temporal_fwd)
+        pack_own = dict(ws=ws, alpha=alpha, bound=eg.hidden_bound(), **eg.temporal_bias_maps(16, 16), **eg.downsample_pack(16, 16))
+        assert "gx_ws" in pack_own and "pixel_bias_dead" in pack_own
+        got_own = eg.forward_channel_last(bev.to(DEV), pack_own)
     assert (got.permute(0, 3, 1, 2).cpu() - ref[0]).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
+    assert (got_own.permute(0, 3, 1, 2).cpu() - ref[0]).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
     # 32 x 32 maps: the stride-2 kernel and the launch-lean ConvGRU (composed matching layer, bias map) are on the path
     enc2 = RadarBEVTemporalEncoder(256, 64, 8).eval()
     for mod in (enc2.convGRU.convGRUCell.gates_conv, enc2.convGRU.convGRUCell.matching_layer, enc2.downsample):
@@ -517,7 +523,9 @@ def test_temporal_encoder_fused_pieces():
         pack2 = dict(ws=ws2, alpha=alpha2, bound=eg2.hidden_bound(), **eg2.downsample_pack(32, 32))
         assert "gru_w" in pack2 and "down_ws" in pack2
         got2 = eg2.forward_channel_last(bev2.to(DEV), pack2)
+        got2_own = eg2.forward_channel_last(bev2.to(DEV), dict(pack2, **eg2.temporal_bias_maps(32, 32)))
     assert (got2.permute(0, 3, 1, 2).cpu() - ref2[0]).abs().max().item() < 2e-5 * ref2.abs().max().item() + 1e-5
+    assert (got2_own.permute(0, 3, 1, 2).cpu() - ref2[0]).abs().max().item() < 2e-5 * ref2.abs().max().item() + 1e-5
 
 
 @pytest.mark.parametrize("rows", [900, 37])

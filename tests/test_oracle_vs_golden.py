@@ -62,6 +62,25 @@ def test_msmv_c_equals_torch(golden_dir):
     assert_close(a, b, 1e-6, 0, "C vs torch msmv")
 
 
+def test_float64_instance_of_the_c_gathers(golden_dir):
+    """The `_f64` instance of oracle/gather_ref.c (the arbiter of tools/fp64_arbiter.py: the same C text compiled for double) against
+    the reference's own fp32 outputs: float64 operands select it, the result is float64 and agrees with the golden to the
+    golden's own fp32 rounding -- and more closely with a float64 evaluation of the torch restatement than with the fp32 one."""
+    if R._clib() is None:
+        pytest.skip("C oracle not built")
+    g = load(golden_dir, "msmv_small.npz")
+    feats = [t(g[f"c2345_feat{i}"]).double() for i in range(4)]
+    out = R.msmv_gather(feats, t(g["c2345_loc"]).double(), t(g["c2345_w"]).double())
+    assert out.dtype == torch.float64
+    assert_close(out, g["c2345_out"], 2e-5, 0, "msmv f64 instance")
+    ref64 = R.msmv_gather_torch(feats, t(g["c2345_loc"]).double(), t(g["c2345_w"]).double()).double()
+    assert float((out - ref64).abs().max()) < 1e-12
+    m = load(golden_dir, "msda_small.npz")
+    o = R.msda(t(m["value"]).double(), m["shapes"].tolist(), [0], t(m["loc"]).double(), t(m["attn"]).double())
+    assert o.dtype == torch.float64
+    assert_close(o, m["out"], 1e-5, 0, "msda f64 instance")
+
+
 def test_sampling_4d_slot_quirk(golden_dir):
     g = load(golden_dir, "sampling4d_small.npz")
     feats = [t(g[f"feat{i}"]) for i in range(4)]

@@ -121,15 +121,25 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const CdArgs a)
     if constexpr (KCH > 0) {
         // weight chunk c -> buffer c & 1: piece q = (tap, tile, row half); lane = (row lane >> 3 of the half, LDS slot lane & 7)
         const int rrow = lane >> 3, rslot = lane & 7;
+        // LDS-DMA as buffer_load ... lds (a buffer descriptor over the weight image), NOT global_load_lds: hipcc books the global form as a
+        // FLAT access that may return out of order, and every vector-memory wait behind one becomes vmcnt(0) -- the 256-channel
+        // downsample, which issues chunk c + 2's pieces inside its K loop, drained its pixel ring and the pieces at every chunk
+        // boundary (ISA reading; the buffer form gets counted waits).  The piece loop is unrolled: a loop of unknown trip count
+        // between a load and its use costs the same vmcnt(0).
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.ws), 0, 9 * KCH * a.Cout * 128, 0x00020000);
         auto dma_chunk = [&](int c) {
-            uint4 *dst = cd_lds + (c & 1) * SLICE;
-            for (int q = wave; q < PIECES; q += 4) {
-                const int tap = q / (2 * NT), rem = q - tap * (2 * NT), nn = rem >> 1, half = rem & 1;
-                const int row = 8 * half + rrow;
-                const int co = MODE == RAC_CD_GRU ? 64 * nn + 16 * cb + row : (cb * NT + nn) * 16 + row;
-                const uint4 *src = a.ws + ((size_t)(tap * KCH + c) * a.Cout + co) * 8 + (rslot ^ ((row >> 1) & 7));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(dst + (tap * NT + nn) * 128 + half * 64), 16, 0, 0);
+            char *dst = reinterpret_cast<char *>(cd_lds + (c & 1) * SLICE);
+#pragma unroll
+            for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+                const int q = wave + 4 * i;
+                if (PIECES % 4 == 0 || q < PIECES) {
+                    const int tap = q / (2 * NT), rem = q - tap * (2 * NT), nn = rem >> 1, half = rem & 1;
+                    const int row = 8 * half + rrow;
+                    const int co = MODE == RAC_CD_GRU ? 64 * nn + 16 * cb + row : (cb * NT + nn) * 16 + row;
+                    const unsigned voff = (unsigned)((((tap * KCH + c) * a.Cout + co) * 8 + (rslot ^ ((row >> 1) & 7))) * 16);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(dst + ((tap * NT + nn) * 128 + half * 64) * 16),
+                                                             16, voff, 0, 0, 0);
+                }
             }
         };
         // A fragments of K step (chunk c, tap): row li of tile nn, hi slot lk, lo slot 4 + lk
@@ -333,9 +343,11 @@ __global__ __launch_bounds__(256) void upsample2x_image_kernel(const float *__re
 
 static bool cd_host_scale_ok(const rac_cd_scale &s) { return s.mul >= 0.f && s.add >= 0.f; }
 
-template <int STRIDE, int NT, int PT, int MODE, int KCH, int D>
-static int cd_launch_d(const CdArgs &a, int attr_id, hipStream_t st)
+template <int STRIDE, int NT, int PT, int MODE, int KCH>
+static int cd_launch(const CdArgs &a, int attr_id, hipStream_t st)
 {
+    // ring depth 3 (measured at 1 / 3 / 9 with tools/exp_convdirect.py: 39.9 / 31.7 / 31.1 us for the downsample, no difference elsewhere)
+    constexpr int D = 3;
     constexpr int lds = KCH > 0 ? 2 * 9 * NT * 128 * 16 : 0;
     const void *fn = reinterpret_cast<const void *>(conv_direct_kernel<STRIDE, NT, PT, MODE, D, KCH>);
     if (lds > 48 * 1024)
@@ -345,18 +357,6 @@ static int cd_launch_d(const CdArgs &a, int attr_id, hipStream_t st)
     const int cblocks = MODE == RAC_CD_GRU ? 4 : a.Cout / (16 * NT);
     hipLaunchKernelGGL((conv_direct_kernel<STRIDE, NT, PT, MODE, D, KCH>), dim3((unsigned)(a.N * ptiles * cblocks)), dim3(256), lds, st, a);
     return 0;
-}
-#include <stdlib.h>
-template <int STRIDE, int NT, int PT, int MODE, int KCH>
-static int cd_launch(const CdArgs &a, int attr_id, hipStream_t st)
-{
-    static const int depth = getenv("RAC_CD_DEPTH") ? atoi(getenv("RAC_CD_DEPTH")) : 3;      // EXPERIMENT switch
-    if constexpr (PT <= 2)
-        if (depth == 9)
-            return cd_launch_d<STRIDE, NT, PT, MODE, KCH, 9>(a, attr_id + 20, st);
-    if (depth == 1)
-        return cd_launch_d<STRIDE, NT, PT, MODE, KCH, 1>(a, attr_id + 40, st);
-    return cd_launch_d<STRIDE, NT, PT, MODE, KCH, 3>(a, attr_id, st);
 }
 
 extern "C" int rac_conv_direct_fwd(const rac_conv_direct *d, void *stream)

@@ -26,7 +26,8 @@ What is compared, and how strictly
      two layers.  The criterion on THAT rig therefore is, separately for the two halves of north_star's statement:
        - class argmax: identical for every query, except a query whose two leading REFERENCE logits are closer together
          than ``ARGMAX_MARGIN[layer]`` = the CPU-vs-CPU logit drift measured for that layer (a tie at the resolution of the
-         arithmetic: neither implementation's argmax is "the" answer there); any other mismatch fails the test;
+         arithmetic: neither implementation's argmax is "the" answer there; since round 5 at most 1.5e-3 in layers 4-5, ten times
+         the largest margin ever used); any other mismatch fails the test;
        - boxes: layers 0-2 within 1e-3 for every query; in layers 3, 4, 5 at most ``TAIL_QUERIES`` = 2, 3, 11 of the 900
          queries may miss 1e-3, none by more than ``TAIL_TOL`` = 2e-2; p50 <= 1e-4 everywhere.
    * SURVEY 8d's SECOND rig -- weights as torch's constructors draw them, then the reference's own init_weights()
@@ -45,12 +46,19 @@ Boxes are compared in the decoder's normalised output space (xyz / pc_range span
 import numpy as np
 import torch
 
+# FROZEN at their round-4 values since round 5 (no longer re-derived from the product's own measurements).  What justifies a tail on
+# this rig is now an INDEPENDENT arbiter: the oracle evaluated in float64 (tools/fp64_arbiter.py, profiles/r05_fp64_arbiter.json).
+# Against it the reference's own fp32 CPU forward misses 1e-3 on 1 / 5, 0 / 3 and 1 / 10 queries in layers 4 / 5 of the three chaotic
+# seeds (worst query 5.9e-3), the GPU on 0 / 4, 0 / 3 and 2 / 10 (worst 9.0e-3); the GPU's median error is 0.87-1.05 x the reference's
+# on every fixture and layer (tests/test_fp64_arbiter_gpu.py asserts <= 1.5 x).  11 = the reference's own 10 + 1.
 TAIL_QUERIES = (0, 0, 0, 2, 3, 11)                    # random-everything rig, per layer: queries (of 900) that may miss 1e-3 on the box
                                                       # (round 4: measured maximum over every comparison of the GPU session + 1 -- 1 / 2 / 10,
                                                       #  profiles/r04_parity_budget_used.json; round 3 allowed 2 / 4 / 12)
 TAIL_BUDGET = tuple(q / 900.0 for q in TAIL_QUERIES)  # ... as a fraction of the queries
 TAIL_TOL = 2e-2                                       # ... and by how much at most (box space; measured maximum 9.9e-3)
-ARGMAX_MARGIN = (4.8e-6, 2.7e-5, 8.8e-5, 2.3e-4, 3.9e-3, 1.2e-2)   # measured CPU-vs-CPU logit drift per layer (see above)
+# measured CPU-vs-CPU logit drift per layer (see above) for layers 0-3; layers 4-5 were 3.9e-3 / 1.2e-2 (that drift's maximum) until
+# round 4 and are now 1.5e-3 = 10 x the largest margin any comparison has ever used (1.5e-4, profiles/r04_parity_budget_used.json)
+ARGMAX_MARGIN = (4.8e-6, 2.7e-5, 8.8e-5, 2.3e-4, 1.5e-3, 1.5e-3)
 # The reference-initialised rig (decoder_f8*_init.npz): its class logits are nearly constant over the queries (the reference's own
 # init leaves the generator / offset / tau weights at zero), so a "tie" has to be judged at THAT rig's arithmetic resolution: the
 # CPU-vs-CPU logit drift measured there is 4.2e-5 in layer 5 (profiles/r03_cpu_vs_cpu_drift.json); x2 as the margin, every layer.

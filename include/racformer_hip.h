@@ -525,34 +525,6 @@ int rac_conv3x3_temporal_fwd(const void *xs, const void *ws, const float *pixel_
                              const float *amax, float w_alpha, float *out, void *q, float *scale, int N, int H, int W, int Cin,
                              int Cin_dead, int frames_per_group, int live_per_group, void *stream);
 
-/* Everything of a decoder layer behind AdaptiveMixing's out_proj as ONE launch (models/racformer_transformer.py:248-262,
- * bev_self_attention.py:215-225): BEV output projections of both streams + identity -> norm_radar_bev / norm_lss_bev ->
- * fusion Linear over [norm2 | radar | lss] -> norm_fusion -> FFN (+ identity) -> norm3 -> cls_branch || reg_branch.
- * A workgroup carries 16 rows through all stages (activations in LDS, weights streamed from L2 into exact-fp32 MFMAs).
- * Built for embed_dims 256, feedforward 512, two hidden layers per branch; every weight in torch's [out][in] layout.
- *   bev   f32 [2][rows][256] (stream stride bev_stream_stride floats): the fused BEV attention outputs BEFORE output_proj
- *   x1    f32 [rows][256] norm1's output (the BEV branches' identity);  x2 f32 [rows][256] norm2's output (rac_add_ln_fwd over
- *         the out_proj partials)
- *   x3_out [rows][256] the layer's output features, cls_out [rows][num_classes], delta_out [rows][code_size] (the input of
- *         rac_layer_boundary_fwd);  probe_* (optional, [rows][256]): proj + identity of the two BEV branches and f + ffn(f) -- the
- *         stage outputs the parity fixtures hold */
-typedef struct {
-    const float *bev;
-    int64_t bev_stream_stride;
-    const float *x1, *x2;
-    const float *bev_w[2], *bev_b[2];
-    const float *nr_g, *nr_b, *nl_g, *nl_b;
-    const float *fus_w, *fus_b, *nf_g, *nf_b;
-    const float *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b, *n3_g, *n3_b;
-    const float *c0r0_w, *c0r0_b, *c1_g, *c1_b, *c3_w, *c3_b, *c4_g, *c4_b, *c6_w, *c6_b;
-    const float *r2_w, *r2_b, *r4_w, *r4_b;
-    float *x3_out, *cls_out, *delta_out;
-    float *probe_radar, *probe_lss, *probe_ffn;
-    int num_classes, code_size;
-    float eps;
-} rac_layer_tail;
-int rac_layer_tail_fwd(const rac_layer_tail *desc, int rows, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -62,7 +62,6 @@ SIGNATURES = {
     "rac_quant_i16_fwd": (_i, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
     "rac_conv_direct_fwd": (_i, [_vp, _vp]),
     "rac_upsample2x_image_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    "rac_layer_tail_fwd": (_i, [_vp, _i, _vp]),
     "rac_conv3x3_temporal_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
 }
 
@@ -99,15 +98,6 @@ class ConvDirect(ctypes.Structure):
                 ("out_frames", CdFrames), ("out_scale", CdScale), ("out_f32", _vp), ("pixel_map", _vp), ("xpart", _vp),
                 ("xpart_frames", CdFrames), ("h_prev", _vp), ("h_prev_frames", CdFrames), ("h_out", _vp),
                 ("h_out_frames", CdFrames)]
-
-
-class LayerTail(ctypes.Structure):
-    """rac_layer_tail (include/racformer_hip.h)"""
-    _fields_ = [("bev", _vp), ("bev_stream_stride", ctypes.c_int64), ("x1", _vp), ("x2", _vp), ("bev_w", _vp * 2), ("bev_b", _vp * 2)] + \
-        [(n, _vp) for n in ("nr_g", "nr_b", "nl_g", "nl_b", "fus_w", "fus_b", "nf_g", "nf_b", "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b",
-                            "n3_g", "n3_b", "c0r0_w", "c0r0_b", "c1_g", "c1_b", "c3_w", "c3_b", "c4_g", "c4_b", "c6_w", "c6_b",
-                            "r2_w", "r2_b", "r4_w", "r4_b", "x3_out", "cls_out", "delta_out", "probe_radar", "probe_lss", "probe_ffn")] + \
-        [("num_classes", _i), ("code_size", _i), ("eps", _f)]
 
 
 CD_IMAGE, CD_F32, CD_GRU = 0, 1, 2

@@ -15,7 +15,7 @@ int rac_set_dynamic_lds_once(int id, const void *func, int bytes);
 enum { RAC_ATTR_GEMM_SPLIT = 0, RAC_ATTR_GENERATOR, RAC_ATTR_CONV3X3, RAC_ATTR_CONV3X3S2, RAC_ATTR_MIXING_F32, RAC_ATTR_MIXING_F16,
        RAC_ATTR_VALUE_PROJ, RAC_ATTR_FPN_CONV, RAC_ATTR_GENERATOR4, RAC_ATTR_CONV3X3_Q16, RAC_ATTR_VALUE_PROJ_Q16, RAC_ATTR_MIXING_SAMPLED,
        RAC_ATTR_CD_GRU, RAC_ATTR_CD_S2_8, RAC_ATTR_CD_S2_2, RAC_ATTR_CD_S2_3, RAC_ATTR_CD_IMG_2, RAC_ATTR_CD_F32_1, RAC_ATTR_CD_F32_2,
-       RAC_ATTR_CD_F32_4, RAC_ATTR_VALUE_PROJ_BIAS, RAC_ATTR_VALUE_PROJ_Q16_BIAS, RAC_ATTR_LAYER_TAIL };
+       RAC_ATTR_CD_F32_4, RAC_ATTR_VALUE_PROJ_BIAS, RAC_ATTR_VALUE_PROJ_Q16_BIAS };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (straight-line code with the index usable in constexpr contexts)
 template <int I>

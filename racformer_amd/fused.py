@@ -667,63 +667,6 @@ def conv3x3_fused(sources, ws, w_alpha, bias, bounds=None, pixel_bias=None):
     return img.conv(ws, w_alpha, bias, pixel_bias)
 
 
-# ------------------------------------------------------------------------------------------- layer tail (round 5)
-def layer_tail_fused(bev, x1, x2, layer, c0r0_w, c0r0_b, cls_out=None, probes=False):
-    """Everything of a decoder layer behind norm2 as one launch (rac_layer_tail_fwd): BEV output projections + identity,
-    norm_radar_bev / norm_lss_bev, fusion, norm_fusion, FFN + identity, norm3, cls_branch || reg_branch.
-    bev [2, rows, 256] (the fused BEV attention outputs before output_proj), x1 / x2 [rows, 256] (norm1 / norm2 outputs), ``layer`` the
-    RaCFormerTransformerDecoderLayer that owns the weights, c0r0_* the concatenated first Linears of the two branches.
-    -> (x3 [rows, 256], cls [rows, classes] (``cls_out`` if given), delta [rows, code], probes dict | None)."""
-    _lib.require_gpu(bev, x1, x2, c0r0_w, c0r0_b, what="layer_tail_fused")
-    rows = x1.shape[0]
-    if tuple(bev.shape) != (2, rows, 256) or tuple(x1.shape) != (rows, 256) or tuple(x2.shape) != (rows, 256):
-        raise RuntimeError("layer_tail_fused: bev [2, rows, 256], x1 / x2 [rows, 256] expected")
-    dev = x1.device
-    cb, rg, w1, w2 = layer.cls_branch, layer.reg_branch, layer.ffn.layers[0][0], layer.ffn.layers[1]
-    ro, lo = layer.sampling_radar_bev.attention.output_proj, layer.sampling_lss_bev.attention.output_proj
-    x3 = torch.empty(rows, 256, device=dev, dtype=torch.float32)
-    cls = cls_out if cls_out is not None else torch.empty(rows, layer.num_classes, device=dev, dtype=torch.float32)
-    if not cls.is_contiguous() or cls.numel() != rows * layer.num_classes:
-        raise RuntimeError("layer_tail_fused: cls_out must be a contiguous [rows, num_classes] tensor")
-    delta = torch.empty(rows, layer.code_size, device=dev, dtype=torch.float32)
-    pr = {k: torch.empty(rows, 256, device=dev, dtype=torch.float32) for k in ("radar", "lss", "ffn")} if probes else None
-    d = _lib.LayerTail()
-    ptr = lambda t: _lib.ptr(t) if t is not None else None          # noqa: E731
-    d.bev, d.bev_stream_stride, d.x1, d.x2 = ptr(bev), int(bev.stride(0)), ptr(x1), ptr(x2)
-    d.bev_w[0], d.bev_w[1], d.bev_b[0], d.bev_b[1] = ptr(ro.weight), ptr(lo.weight), ptr(ro.bias), ptr(lo.bias)
-    for name, t in (("nr_g", layer.norm_radar_bev.weight), ("nr_b", layer.norm_radar_bev.bias), ("nl_g", layer.norm_lss_bev.weight),
-                    ("nl_b", layer.norm_lss_bev.bias), ("fus_w", layer.fusion.weight), ("fus_b", layer.fusion.bias),
-                    ("nf_g", layer.norm_fusion.weight), ("nf_b", layer.norm_fusion.bias), ("ffn1_w", w1.weight), ("ffn1_b", w1.bias),
-                    ("ffn2_w", w2.weight), ("ffn2_b", w2.bias), ("n3_g", layer.norm3.weight), ("n3_b", layer.norm3.bias),
-                    ("c0r0_w", c0r0_w), ("c0r0_b", c0r0_b), ("c1_g", cb[1].weight), ("c1_b", cb[1].bias), ("c3_w", cb[3].weight),
-                    ("c3_b", cb[3].bias), ("c4_g", cb[4].weight), ("c4_b", cb[4].bias), ("c6_w", cb[6].weight), ("c6_b", cb[6].bias),
-                    ("r2_w", rg[2].weight), ("r2_b", rg[2].bias), ("r4_w", rg[4].weight), ("r4_b", rg[4].bias),
-                    ("x3_out", x3), ("cls_out", cls), ("delta_out", delta),
-                    ("probe_radar", pr["radar"] if pr else None), ("probe_lss", pr["lss"] if pr else None),
-                    ("probe_ffn", pr["ffn"] if pr else None)):
-        setattr(d, name, ptr(t))
-    d.num_classes, d.code_size, d.eps = int(layer.num_classes), int(layer.code_size), float(layer.norm3.eps)
-    ev = _lib.timer.record("layer_tail_fwd") if _lib.timer is not None else None
-    if ev:
-        ev[0].record()
-    rc = _lib.lib().rac_layer_tail_fwd(ctypes.byref(d), rows, _lib.stream_ptr())
-    if ev:
-        ev[1].record()
-    _lib.check(rc, "rac_layer_tail_fwd")
-    return x3, cls, delta, pr
-
-
-def layer_tail_supported(layer):
-    """The one-launch tail is built for the reference's shapes: embed 256, FFN 512, two hidden layers per branch, one LayerNorm eps."""
-    cb, rg = layer.cls_branch, layer.reg_branch
-    w1, w2 = layer.ffn.layers[0][0], layer.ffn.layers[1]
-    norms = [layer.norm_radar_bev, layer.norm_lss_bev, layer.norm_fusion, layer.norm3, cb[1], cb[4]]
-    return (layer.embed_dims == 256 and len(cb) == 7 and len(rg) == 5 and tuple(w1.weight.shape) == (512, 256)
-            and tuple(w2.weight.shape) == (256, 512) and tuple(layer.fusion.weight.shape) == (256, 768)
-            and all(abs(n.eps - norms[0].eps) == 0 and n.elementwise_affine for n in norms)
-            and all(m.bias is not None for m in (w1, w2, layer.fusion, cb[0], cb[3], cb[6], rg[0], rg[2], rg[4])))
-
-
 # ------------------------------------------------------------------------------------------- ConvGRU branch, own kernels (round 5)
 def act_image(tag, frames, H, W, channels, device):
     """A zero-bordered activation image f16 [frames, H+2, W+2, channels/32, 2, 32] of the convolution kernels, from the reusable

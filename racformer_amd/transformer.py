@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import _lib
 from .bbox_utils import decode_bbox, inverse_sigmoid, theta_d2xy_coods, xy2theta_d_coods
 from .fused import (SPLIT_ACT_SCALE, SPLIT_BIAS_PAD, SPLIT_SLICE, ConvImage, act_image, add_ln, bev_sampling_fused, bev_sampling_multi_fused,
-                    box_prep, conv_direct, layer_tail_fused, layer_tail_supported, quantize_values_i16, upsample2x_image,
+                    box_prep, conv_direct, quantize_values_i16, upsample2x_image,
                     generator_fused, gru_gate_fused, layer_boundary_fused, mixing_fused, mixing_sampled_fused, mixing_sampled_supported, outproj_fused,
                     pack_conv3x3_weight,
                     pack_gemm_split_weight,
@@ -1001,9 +1001,6 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # boundary launch to the next call; the decoder clears it before layer 0, and it is only honoured for the matching
         # layer index and (live, unmodified) tensor
         self._carry = None
-        # everything behind norm2 (BEV output projections .. cls / reg branches) as ONE launch, a workgroup per 16-row tile
-        # (rac_layer_tail_fwd, csrc/layer_tail.hip); False: the seven rac_rowgemm_fwd launches of rounds 2-4
-        self.fused_tail = True
         # radar stream: value_proj composed into the temporal-fusion convolution (BEVSampling.composed_value_pack)
         self.compose_radar_value = True
         # storage of the two hoisted BEV value streams (value_proj's outputs): "f32" (default, the reference's fp32 maps,
@@ -1285,39 +1282,6 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
             sampled_feat = self._sample(qb, x1, mlvl_feats, img_metas, d_region, lin[0:3], table)
             partials = self.mixing.out_proj_partials(sampled_feat, x1, prepared["out_proj_split"], None, packs, x1_split)
         p_scale = packs["out_alpha"] if packs else 1.0
-        x2 = add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0],
-                    a_scale=p_scale)
-        if self.fused_tail and layer_tail_supported(self):
-            x3f, cls_score, delta, probes = layer_tail_fused(bev.view(2, n, E), x1.view(n, E), x2.view(n, E), self, prepared["c0r0_w"],
-                                                             prepared["c0r0_b"], cls_out=out_slots[0] if out_slots is not None else None,
-                                                             probes=stages is not None)
-            x3, cls_score, delta = x3f.view(B, Q, E), cls_score.view(B, Q, self.num_classes), delta.view(B, Q, self.code_size)
-            tail_stages = None if probes is None else dict(sampling_radar_bev=probes["radar"].view_as(x1),
-                                                           sampling_lss_bev=probes["lss"].view_as(x1), ffn=probes["ffn"].view_as(x1))
-        else:
-            x3, cls_score, delta, tail_stages = self._tail_rowgemm(bev, x1, x2, prepared, out_slots, stages is not None)
-        # refine_bbox of this layer + box table and position-encoder head of the next one, one launch
-        bbox_pred, bbox_xy, next_table, next_h = layer_boundary_fused(qb, delta, meta["time_diff_safe"], self.num_ray,
-                                                                      self.pc_range, pe[0], pe[1],
-                                                                      xy_out=out_slots[1] if out_slots is not None else None)
-        self.wrote_slots = out_slots is not None
-        # (the carry holds bbox_pred itself: its storage cannot be freed and handed to another tensor while the key is live)
-        self._carry = ((layer + 1, bbox_pred.data_ptr(), tuple(bbox_pred.shape), bbox_pred._version), next_h, next_table, bbox_pred)
-        if stages is not None:
-            mixed = x1 + p_scale * partials.sum(0).view_as(x1) + self.mixing.out_proj.bias
-            stages.update(position_encoder=x - query_feat, self_attn=x + attn.view_as(x), sampling=sampled_feat, mixing=mixed,
-                          **tail_stages)
-        self.last_bbox_xy = bbox_xy
-        return x3, cls_score, bbox_pred
-
-    def _tail_rowgemm(self, bev, x1, x2, prepared, out_slots, want_stages):
-        """The layer behind norm2 as seven rac_rowgemm_fwd launches (rounds 2-4; the plan for shapes rac_layer_tail_fwd is not built
-        for, and its cross-check in the tests): -> (x3, cls_score, delta, stage probes | None)."""
-        B, Q, E = x1.shape
-        n = B * Q
-        dev = x1.device
-        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)   # noqa: E731
-        rb, lb = self.sampling_radar_bev, self.sampling_lss_bev
         # both BEV output projections in one launch
         proj = new(2, n, E)
         ro, lo = rb.attention.output_proj, lb.attention.output_proj
@@ -1326,6 +1290,8 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         # fusion Linear over [norm2(mixing) | norm_radar(radar) | norm_lss(lss)]: the split-K sum + norm2 is its own row-wise
         # launch (16 partial rows per row are latency-bound inside a GEMM prologue: 32 us against 5 + 15), the two BEV
         # thirds are normalised in the GEMM's prologue
+        x2 = add_ln(partials, self.norm2, residual=x1, bias=self.mixing.out_proj.bias, num_partials=partials.shape[0],
+                    a_scale=p_scale)
         # The fusion Linear (K = 768) as three 256-deep GEMMs side by side in one launch (3 x 228 workgroups, each with a
         # third of the prologue and of the k-loop); its consumer sums the three partial outputs in its prologue.
         fk, f2k = prepared["fusion_k"], prepared["ffn2_k"]
@@ -1353,9 +1319,20 @@ class RaCFormerTransformerDecoderLayer(nn.Module):
         delta = new(B, Q, self.code_size)
         rowgemm_launch([row_gemm([row_seg(c3, norm=cb[4], relu=True)], cb[6].weight, cb[6].bias, cls_score),
                         row_gemm([row_seg(r2)], rg[4].weight, rg[4].bias, delta)], n)
-        tail_stages = dict(sampling_radar_bev=proj[0].view_as(x1) + x1, sampling_lss_bev=proj[1].view_as(x1) + x1,
-                           ffn=(f + ffn_parts.sum(0)).view_as(x1)) if want_stages else None
-        return x3, cls_score, delta, tail_stages
+        # refine_bbox of this layer + box table and position-encoder head of the next one, one launch
+        bbox_pred, bbox_xy, next_table, next_h = layer_boundary_fused(qb, delta, meta["time_diff_safe"], self.num_ray,
+                                                                      self.pc_range, pe[0], pe[1],
+                                                                      xy_out=out_slots[1] if out_slots is not None else None)
+        self.wrote_slots = out_slots is not None
+        # (the carry holds bbox_pred itself: its storage cannot be freed and handed to another tensor while the key is live)
+        self._carry = ((layer + 1, bbox_pred.data_ptr(), tuple(bbox_pred.shape), bbox_pred._version), next_h, next_table, bbox_pred)
+        if stages is not None:
+            mixed = x1 + p_scale * partials.sum(0).view_as(x1) + self.mixing.out_proj.bias
+            stages.update(position_encoder=x - query_feat, self_attn=x + attn.view_as(x),
+                          sampling_radar_bev=proj[0].view_as(x1) + x1, sampling_lss_bev=proj[1].view_as(x1) + x1,
+                          sampling=sampled_feat, mixing=mixed, ffn=(f + ffn_parts.sum(0)).view_as(x1))
+        self.last_bbox_xy = bbox_xy
+        return x3, cls_score, bbox_pred
 
     def forward_fused_chain(self, query_bbox, query_feat, mlvl_feats, img_metas, layer, prepared, stages=None):
         """The layer as a chain of library GEMMs and hand-written HIP kernels only: every LayerNorm is fused

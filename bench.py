@@ -471,7 +471,18 @@ def main():
                 captured.replay(img_metas=metas)
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
+            # GPU-side duration of ONE replay alone on the chip (first kernel's start to last kernel's end, HIP events on the replay's
+            # stream, median of 20 single replays): what a sample's kernels take without another sample beside them
+            evs = []
+            for _ in range(20):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                captured.replay(img_metas=metas)
+                e1.record()
+                torch.cuda.synchronize()
+                evs.append(e0.elapsed_time(e1))
             single = {"value": args.steps / dt1, "unit": "samples/s", "ms_per_step": 1e3 * dt1 / args.steps,
+                      "gpu_ms_per_replay_alone": statistics.median(evs),
                       "note": "one captured plan in flight (each sample's kernels run alone): per-sample latency"}
         _lib.timer = _lib.KernelTimer(only=("sampling4d_fwd", "mixing_sampled_fwd", "msmv_fwd"))
         for _ in range(args.steps):
@@ -500,8 +511,8 @@ def main():
         elapsed = max(float(t.item()) for t in allr)      # max over ranks
         merged = dp.merge_interleaved(out, world)           # one sample per rank per step, dataset order
         assert tuple(merged.shape) == (world, 300, 11)
-    # the dominant kernel: since round 4 the adaptive sampling runs INSIDE the mixing kernel (rac_mixing_sampled_fwd); with
-    # decoder_layer.fuse_sampling_mixing = False it is the stand-alone sampling kernel of rounds 1-4
+    # the dominant kernel: the stand-alone sampling kernel (rac_sampling4d_fwd); with decoder_layer.fuse_sampling_mixing = True
+    # (RAC_FUSE_SAMPLING_MIXING=1: measured and rejected in round 4) the sampling runs inside the mixing kernel
     fused_sm = bool(timer.mean_ms("mixing_sampled_fwd"))
     msmv_ms = timer.mean_ms("mixing_sampled_fwd") or timer.mean_ms("sampling4d_fwd") or timer.mean_ms("msmv_fwd")
     bev_streams = 2 if aux.mean_ms("bev_sampling_x2_fwd") else 1        # radar + LSS in one launch
@@ -608,6 +619,12 @@ def main():
                    "distinct_inputs_per_lane": bool(lanes) and not args.same_inputs_per_lane,
                    "sample_seeds_this_rank": [seed + i for i in range(len(lanes) or 1)] if not args.same_inputs_per_lane else [seed],
                    "parallelism": f"dp{world}", "bev_value_stream_storage": "int16-block" if args.value_storage == "i16" else "f32",
+                   # the figures a reader of the driver's record needs beside `value` (the driver keeps this dict whole):
+                   # the reference's own evaluation semantics are one sample at a time (val.py:133-136)
+                   "one_sample_in_flight_samples_per_s": single["value"] if single else None,
+                   "one_sample_in_flight_ms_per_sample": single["ms_per_step"] if single else None,
+                   "kernel_ms_per_sample_one_plan": single.get("gpu_ms_per_replay_alone") if single else None,
+                   "lanes_match_single_plan_bitwise": lanes_match,
                    "pyramid_layout": "pregrouped [B*T*G,N,H,W,C]" if args.pregrouped else "reference [B,T*N,G*C,H,W] (regroup timed)"},
         "roofline": {"bound": "hbm", "kernel": "mixing_c64_f16x3_kernel<4> (rac_mixing_sampled_fwd: keypoints + projection + view select + gather "
                                "of the item's 96 points AND both adaptive mixings + LayerNorms, one launch per layer)" if fused_sm else
@@ -637,6 +654,12 @@ def main():
                      "sasa_avg_launch_ms": sasa_ms},
         "mfma": mfma,
     }
+    if world > 1:
+        # the CPU oracle and the operator stress set are timed on rank 0 of a ONE-rank run only (they would sit inside the other
+        # ranks' barrier otherwise); the line says so instead of omitting the keys
+        result["cpu_baseline"] = None
+        result["cpu_baseline_note"] = "measured at --gpus 1 only (rank 0 of a single-rank run); see the N = 1 line of the same build"
+        result["roofline_stress"] = None
     if rank == 0 and world == 1 and not args.no_stress:
         result["roofline_stress"] = stress_block(cfg, device)
 
@@ -728,7 +751,7 @@ def main():
         sd = {k: v.detach().cpu() for k, v in head.transformer.state_dict().items()}
         hsd = {k: v.detach().cpu() for k, v in head.state_dict().items() if not k.startswith("transformer.")}
         cpu_pyr = [f.cpu() for f in pyramid]
-        warm, reps = 1, 5      # ~25-30 s of CPU work on the 16-core share (bounded sample; BASELINE.md plans 3 + 10 in the container)
+        warm, reps = 3, 5      # ~35 s of CPU work on the 16-core share (bounded sample; SURVEY 8d plans 3 warm-ups + 10 in the container)
         times = []
         R.LOC_TAP = []
         with torch.no_grad():

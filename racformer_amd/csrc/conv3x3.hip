@@ -591,7 +591,12 @@ extern "C" int rac_absmax_fwd(const float *const *srcs, const int64_t *counts, i
     RAC_CHECK_ARG(num >= 0 && amax_out && floor_value >= 0.f, "rac_absmax_fwd: bad arguments");
     unsigned floor_bits;
     memcpy(&floor_bits, &floor_value, sizeof(floor_bits));
+#if defined(RAC_ABSMAX_MEMSET) && defined(RAC_DIAGNOSTIC_BUILD)
+    // diagnostic builds only (tools/graph_memset_edges.py): round 3's reset of the scale word, a graph MEMSET node when captured
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(amax_out), (int)floor_bits, 1, (hipStream_t)stream);
+#else
     hipLaunchKernelGGL(absmax_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned *>(amax_out), floor_bits);
+#endif
     for (int i = 0; i < num; ++i) {
         RAC_CHECK_ARG(counts[i] >= 0 && (counts[i] == 0 || srcs[i]), "rac_absmax_fwd: source %d", i);
         RAC_CHECK_ARG(((uintptr_t)srcs[i] & 15) == 0, "rac_absmax_fwd: source %d is not 16-byte aligned", i);

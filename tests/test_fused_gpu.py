@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+import plans
 from oracle import restate as R
 from racformer_amd import synthetic as syn
 from racformer_amd.transformer import RaCFormerTransformer
@@ -37,7 +38,7 @@ def test_sampling4d_fused(cfg):
     d_region = cfg.d_region_list[2]
     with torch.no_grad():
         out, loc, w = layer.sampling(qb.to(DEV), qf.to(DEV), feats, metas, d_region=d_region, debug=True)
-        out_unf = layer.sampling.forward_unfused(qb.to(DEV), qf.to(DEV), feats, metas, d_region=d_region)
+        out_unf = plans.sampling_reference_ops(layer.sampling, qb.to(DEV), qf.to(DEV), feats, metas, d_region=d_region)
         td = R.time_diff_from_metas(syn.make_img_metas(cfg), cfg.batch, cfg.num_cams)
         l2i = torch.from_numpy(np.asarray([m["lidar2img"] for m in syn.make_img_metas(cfg)]).astype(np.float32))
         pts, sw = R.image_keypoints(sd, qb, qf, td, d_region, cfg)
@@ -171,7 +172,7 @@ def test_bev_sampling_fused(cfg):
         with torch.no_grad():
             value, hw = mod.prepare_value(lss.to(DEV))
             got = mod.attend_prepared(qb.to(DEV), qf.to(DEV), value, hw, metas[0]["time_diff"], d_region)
-            unf = mod.attend_prepared_unfused(qb.to(DEV), qf.to(DEV), value, hw, metas[0]["time_diff"], d_region)
+            unf = plans.bev_attend_reference_ops(mod, qb.to(DEV), qf.to(DEV), value, hw, metas[0]["time_diff"], d_region)
             ref = R.bev_sampling(sd, name, qb, qf, lss, td, d_region, cfg, temp)
         torch.cuda.synchronize()
         assert (got.cpu() - ref).abs().max().item() < 2e-4, name

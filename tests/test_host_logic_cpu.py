@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+import plans  # noqa: F401  (registers the reference's op decomposition: decoder_layer.fused = False)
 from oracle import restate as R
 from parity import decoder_parity
 from racformer_amd import synthetic as syn

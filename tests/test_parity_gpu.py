@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+import plans  # noqa: F401  (registers the alternate execution plans: decoder_layer.fused / .rowgemm = False)
 from oracle import restate as R
 from parity import (ARGMAX_MARGIN_INIT_RIG, decode_parity, decoder_parity, detections_parity, fill_rig_module, flipped_points, head_boxes_normalised,
                     kept_rows, oracle_decoder, run_with_reference_views, teacher_forced_layer_check)

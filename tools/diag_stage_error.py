@@ -11,6 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+import plans  # noqa: E402,F401  (registers the alternate execution plans)
 from oracle import restate as R  # noqa: E402
 from racformer_amd import synthetic as syn  # noqa: E402
 from racformer_amd.transformer import RaCFormerTransformer, regroup_pyramid  # noqa: E402

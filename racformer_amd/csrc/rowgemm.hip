@@ -248,10 +248,12 @@ extern "C" int rac_rowgemm_fwd(const rac_rowgemm *descs, int num, int rows, void
         max_seg = d.num_seg > max_seg ? d.num_seg : max_seg;
     }
     a.rows = rows;
+    hipStream_t st = (hipStream_t)stream;
+    // (round 5, measured and rejected: 32-row tiles (MT = 2) for the 512-wide single-segment layers -- 232 workgroups, one per CU,
+    //  instead of 456 at two per CU: one plan in flight 230.8 -> 227.8 samples/s, four plans unchanged)
     const int R = 16;
     const size_t lds = (size_t)R * (256 * max_seg + 4) * sizeof(float);
     const dim3 grid((rows + R - 1) / R, (max_n + 63) / 64, num);
-    hipStream_t st = (hipStream_t)stream;
     if (max_seg == 1 && (long)grid.x * grid.y * grid.z > 512)
         hipLaunchKernelGGL((rowgemm_kernel<1, 1, false>), grid, dim3(256), lds, st, a);   // many workgroups: occupancy first
     else if (max_seg == 1)

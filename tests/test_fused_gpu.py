@@ -615,7 +615,7 @@ def test_conv3x3_stride2_kernel(shape):
     assert (got.double().cpu() - want).abs().max().item() <= tol * want.abs().max().item()
 
 
-@pytest.mark.parametrize("F_,H,W", [(8, 128, 128), (3, 16, 16), (1, 8, 4)])
+@pytest.mark.parametrize("F_,H,W", [(8, 128, 128), (3, 16, 16), (1, 8, 4), (2, 96, 100), (5, 24, 40)])  # 300 blocks: some workgroups take two; 30: fewer than CUs
 def test_value_proj_kernel_vs_float64(F_, H, W):
     """rac_value_proj_fwd (transpose + per-pixel hi / lo split + split-precision GEMM + additive term in one kernel) against
     float64, with channels and pixels of very different magnitude (the activation scale is chosen per pixel), an all-zero
@@ -678,7 +678,7 @@ def test_conv3x3_q16_epilogue_is_the_quantiser_of_the_fp32_output(N, H, W, pixel
     assert int(q[:, :, 2].abs().max()) == 0 and int(q[:, :, 0].abs().max()) >= 16384      # the zero head; full-range mantissas elsewhere
 
 
-@pytest.mark.parametrize("F_,H,W", [(8, 128, 128), (3, 16, 16), (1, 8, 4)])
+@pytest.mark.parametrize("F_,H,W", [(8, 128, 128), (3, 16, 16), (1, 8, 4), (2, 96, 100), (5, 24, 40)])  # 300 blocks: some workgroups take two; 30: fewer than CUs
 def test_value_proj_q16_epilogue_is_the_quantiser_of_the_fp32_output(F_, H, W):
     """rac_value_proj_q16_fwd against rac_quant_i16_fwd(rac_value_proj_fwd(.)): bit for bit (the block maximum of a head is
     combined across the two waves that hold its 64 features)."""

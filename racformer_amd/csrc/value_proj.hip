@@ -18,11 +18,16 @@
 // 32w .. 32w+31 of the 32 pixels (lane = pixel quad x channel quad: 4 x float4), the per-pixel maxima are combined across
 // the waves through LDS, and the scaled hi / lo values go to LDS in the fragment layout of gemm_split.hip (1 KB per pixel,
 // 16-byte chunk c at slot c ^ (pixel & 15)).
-// Round 5: the pixels come through an LDS-DMA ring of raw fp32 stages (global_load_lds_dwordx4, VP_RING stages of 32 KB, each wave
-// its own 4 KB of a stage: no barrier between a wave's DMA and its own reads), issued VP_RING stages ahead.  Rounds 2-4 loaded
-// the next stage into registers under the MFMAs: with 252 VGPRs there was room for ONE stage, i.e. 32 KB in flight per CU, and at
-// ~2.5 us of loaded HBM latency that is 13 GB/s per CU = 3.3 TB/s chip-wide -- the kernel's 99-113 us.  (Round 4 had blamed the two
-// barriers per stage.)
+// Round 5: the pixels come through an LDS-DMA ring of raw fp32 stages (buffer_load ... lds, VP_RING stages of 32 KB, each wave its own
+// 4 KB of a stage: no barrier between a wave's DMA and its own reads), issued VP_RING stages ahead.  Rounds 2-4 loaded the next stage
+// into registers under the MFMAs: with 252 VGPRs there was room for ONE stage.
+// Where the time is (profiles/r05_value_proj_phases.json, tools/vp_phase_split.py): the wait for a stage's pixels is ZERO -- not an HBM
+// wait.  A stage is 4.0 us: raw rows + in-wave maxima 0.4, exchange of the maxima + hi / lo image 0.6-0.8, piece issue 0.2, MFMAs
+// 1.0-1.7 (the matrix pipes need 1.48 for the two waves of a SIMD), epilogue 0.3, two barriers; every phase but the MFMAs is a chain
+// of LDS round trips that two waves per SIMD cannot hide (the weights fill the register file: no third wave).  Ablations: without
+// MFMAs 91 us, without stores 84, without ANY pixel load 83 of 98 (cold caches).  Building image s + 1 under the MFMAs of stage s,
+// with the two waves of a SIMD in opposite order, was measured and rejected (profiles/r05_value_proj_phases_pipelined_rejected.json:
+// 102 us, every side took as long beside the other as alone).
 #include "rac_common.h"
 
 typedef _Float16 vp_h8 __attribute__((ext_vector_type(8)));

@@ -455,6 +455,10 @@ def main():
     elapsed = time.perf_counter() - t0
     single = lanes_match = None
     if captured is not None:
+        if not lanes:
+            # --in-flight 1: the timed region itself is the one-plan figure (per rank)
+            single = {"value": args.steps / elapsed, "unit": "samples/s", "ms_per_step": 1e3 * elapsed / args.steps,
+                      "note": "the timed region itself (one captured plan in flight)"}
         if lanes:
             # every lane ran a sample of its own beside the others: what its last replay left must be, bit for bit, what ONE plan
             # alone produces on that lane's sample -- the eager step (one launch per kernel, nothing else on the GPU), computed here,

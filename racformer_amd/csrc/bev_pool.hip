@@ -12,7 +12,9 @@
 // butterfly inside the group.  No atomics: every output element has exactly one writer (deterministic).
 #include "rac_common.h"
 
-template <int LANES>
+// WHOLE: c is a multiple of 4 * LANES -- every lane owns a channel quad in every pass; the predicate folds away (with it in place the
+// four row loads of a batch sat behind exec-mask branches of their own: 55 -> 67 us on the f8 Lift-Splat shape).
+template <int LANES, bool WHOLE>
 __global__ __launch_bounds__(256) void bev_pool_fwd_kernel(int c, int n_intervals, const float *__restrict__ depth,
                                                            const float *__restrict__ feat, const int *__restrict__ ranks_depth,
                                                            const int *__restrict__ ranks_feat, const int *__restrict__ ranks_bev,
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_kernel(int c, int n_interval
     // shuffle from a disabled lane reads 0 -- those points silently dropped out of the sum.
     for (int cb = 0; cb < c; cb += LANES * 4) {
         const int c0 = cb + ln * 4;
-        const bool mine = c0 < c;
+        const bool mine = WHOLE || c0 < c;
         rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int base = 0; base < len; base += LANES) {
             const int n = min(LANES, len - base);
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_generic_kernel(int c, int n_
     out[(size_t)ranks_bev[start] * c + cur_c] = psum;
 }
 
-template <int LANES>
+template <int LANES, bool WHOLE>
 __global__ __launch_bounds__(256) void bev_pool_bwd_kernel(int c, int n_intervals, const float *__restrict__ out_grad,
                                                            const float *__restrict__ depth, const float *__restrict__ feat,
                                                            const int *__restrict__ ranks_depth, const int *__restrict__ ranks_feat,
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_kernel(int c, int n_interval
     if (live)
         for (int cb = 0; cb < c; cb += LANES * 4) {
             const int c0 = cb + ln * 4;
-            const bool mine = c0 < c;
+            const bool mine = WHOLE || c0 < c;
             rac_f4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int base = 0; base < len; base += LANES) {
                 const int n = min(LANES, len - base);
@@ -225,7 +227,8 @@ extern "C" int rac_bev_pool_v2_fwd(const float *depth, const float *feat, float 
                   "rac_bev_pool_v2_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int lanes = pool_lanes(c);
-#define POOL_FWD(L_) hipLaunchKernelGGL(bev_pool_fwd_kernel<L_>, dim3((unsigned)(((long)n_intervals * L_ + 255) / 256)), dim3(256), 0, st, \
+#define POOL_FWD(L_) do { POOL_FWD2(L_, true); else POOL_FWD2(L_, false); } while (0)
+#define POOL_FWD2(L_, W_) if ((c % (4 * L_) == 0) == W_) hipLaunchKernelGGL((bev_pool_fwd_kernel<L_, W_>), dim3((unsigned)(((long)n_intervals * L_ + 255) / 256)), dim3(256), 0, st, \
                                         c, n_intervals, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out)
     if (lanes == 64) POOL_FWD(64);
     else if (lanes == 32) POOL_FWD(32);
@@ -234,6 +237,7 @@ extern "C" int rac_bev_pool_v2_fwd(const float *depth, const float *feat, float 
         hipLaunchKernelGGL(bev_pool_fwd_generic_kernel, dim3((unsigned)(((long)n_intervals * c + 255) / 256)), dim3(256), 0, st, c,
                            n_intervals, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out);
 #undef POOL_FWD
+#undef POOL_FWD2
     return rac_launch_status("rac_bev_pool_v2_fwd");
 }
 
@@ -250,7 +254,8 @@ extern "C" int rac_bev_pool_v2_bwd(const float *out_grad, float *depth_grad, flo
                   "rac_bev_pool_v2_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int lanes = pool_lanes(c);
-#define POOL_BWD(L_) hipLaunchKernelGGL(bev_pool_bwd_kernel<L_>, dim3((unsigned)(((long)n_intervals * L_ + 255) / 256)), dim3(256), 0, st, \
+#define POOL_BWD(L_) do { POOL_BWD2(L_, true); else POOL_BWD2(L_, false); } while (0)
+#define POOL_BWD2(L_, W_) if ((c % (4 * L_) == 0) == W_) hipLaunchKernelGGL((bev_pool_bwd_kernel<L_, W_>), dim3((unsigned)(((long)n_intervals * L_ + 255) / 256)), dim3(256), 0, st, \
                                         c, n_intervals, out_grad, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,      \
                                         interval_lengths, depth_grad, feat_grad)
     if (lanes == 64) POOL_BWD(64);
@@ -261,5 +266,6 @@ extern "C" int rac_bev_pool_v2_bwd(const float *out_grad, float *depth_grad, flo
                            out_grad, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, depth_grad,
                            feat_grad);
 #undef POOL_BWD
+#undef POOL_BWD2
     return rac_launch_status("rac_bev_pool_v2_bwd");
 }

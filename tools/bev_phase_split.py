@@ -48,12 +48,17 @@ def main():
     rc = fn(buf.ctypes.data_as(ctypes.c_void_p), n)
     if rc != 0:
         raise SystemExit(f"rac_dbg_bev_stamps rc={rc}")
-    t = buf[:, :5].astype(np.int64)
+    t = buf[:, :7].astype(np.int64)
     t0 = t[:, 0].min()
-    t -= t0
+    merged = bool((t[:, 6] > 0).all())      # the tap-merging variant stamps the end of phase B2 (slot 6; slot 5 is the placement word)
+    t[:, [0, 1, 2, 3, 4, 6]] -= t0
     span = int(t[:, 4].max())
-    phases = {"A_prologue": t[:, 1] - t[:, 0], "B_keypoints_taplists": t[:, 2] - t[:, 1], "C_gather": t[:, 3] - t[:, 2],
-              "D_sum_store": t[:, 4] - t[:, 3]}
+    if merged:
+        phases = {"A_prologue": t[:, 1] - t[:, 0], "B_keypoints_records": t[:, 2] - t[:, 1], "B2_merge_taps": t[:, 6] - t[:, 2],
+                  "C_gather": t[:, 3] - t[:, 6], "D_sum_store": t[:, 4] - t[:, 3]}
+    else:
+        phases = {"A_prologue": t[:, 1] - t[:, 0], "B_keypoints_taplists": t[:, 2] - t[:, 1], "C_gather": t[:, 3] - t[:, 2],
+                  "D_sum_store": t[:, 4] - t[:, 3]}
     life = t[:, 4] - t[:, 0]
     hw = buf[:, 5]
     xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF

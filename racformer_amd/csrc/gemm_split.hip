@@ -276,6 +276,25 @@ struct GenArgs {
 //            64 KB ring each.  The two waves of a SIMD now belong to different workgroups with barriers of their own, so they drift
 //            out of phase and one multiplies while the other is between stages.  Every workgroup still streams the whole X image
 //            (0.9 MB, L2-resident), so the LDS-DMA intake per CU doubles (1.8 MB per launch).
+// Diagnostic build only (tools/gen_phase_split.py; -DGW_STAMPS): s_memtime at four points of every stage, waves 0 and 5 of the first 256 workgroups.
+#if defined(RAC_DIAGNOSTIC_BUILD) && defined(GW_STAMPS)
+#define GW_STAMP_STAGES 32
+__device__ unsigned long long gw_stamp_buf[256 * 2 * GW_STAMP_STAGES * 6];
+#define GW_STAMP(i)                                                                                                          \
+    do {                                                                                                                     \
+        if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 5) && st < GW_STAMP_STAGES && blockIdx.x < 256 && blockIdx.y == 0) \
+            gw_stamp_buf[((blockIdx.x * 2 + (wave != 0)) * GW_STAMP_STAGES + st) * 6 + (i)] =                                    \
+                (i) == 5 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();                                     \
+    } while (0)
+extern "C" int rac_dbg_gw_stamps(unsigned long long *host_out)
+{
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gw_stamp_buf), sizeof(gw_stamp_buf), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define GW_STAMP(i)
+#endif
+
 template <int WAVES, int ROWS>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void generator_ws_kernel(const GenArgs g)
 {
@@ -351,6 +370,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void generator_ws_k
         // issue comes AFTER the MFMA block: at the loop's back edge hipcc cannot match the pending LDS-DMAs with the slots they
         // target and drains vmcnt before the trip's first fragment read -- with the new pieces not yet issued that costs
         // nothing (the older ones have landed), with them issued it exposed one full memory latency every four stages
+        GW_STAMP(0);
         if (u != 0 && st + 3 < nstages)
             issue(st + 3, (u + 3) & (GW_STAGES - 1));
         const char *S = lds + (u & (GW_STAGES - 1)) * STAGE;
@@ -396,9 +416,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void generator_ws_k
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        GW_STAMP(1);
         if (u == 0 && st + 3 < nstages)
             issue(st + 3, 3);
         // C/D layout: col = li (X row), rows 4 lk + r = four consecutive features: one 16-byte store each
+        // (Round 5, stamps of tools/gen_phase_split.py, profiles/r05_generator_phases.json: a stage is 2.58 us = MFMA block 1.25 us on the
+        //  wave of a SIMD that gets the pipe first, 1.87 us on its partner (1.55 us is the pipes' own time for the two) + this epilogue
+        //  0.32-0.36 + the counted wait 0.13 + the barrier.  Tried and rejected: a second accumulator set with this epilogue moved INTO
+        //  the next stage's MFMA block (256 VGPRs; 87.3 us against 89.4: the block grew by what the epilogue took, a wave issues in
+        //  order and its stores hold back its MFMAs), and the same with the two waves of a SIMD doing it at different K steps
+        //  (3 spilled dwords: 103.6 us).)
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int row = m0 + st * ROWS + 16 * j + li;
@@ -423,6 +450,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void generator_ws_k
         // 3 * 2J + 2 * 4 younger operations may then remain outstanding behind P(st+1) (fewer pieces follow towards the end).
         // Any other wave (features at or beyond N in the last feature block, a partial last row stage: the compiler branches
         // around stores no lane takes) issues an unknown number of stores: it may only leave the pieces themselves outstanding.
+        GW_STAMP(2);
         const bool all_stores = full_n && (st + 1) * ROWS <= mrows;     // wave-uniform
         if (all_stores) {
             if (J == 2) {
@@ -448,7 +476,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void generator_ws_k
             else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
+        GW_STAMP(3);
         __builtin_amdgcn_s_barrier();
+        GW_STAMP(4);
+        GW_STAMP(5);
     }
     }
     RAC_CLOCK_END(generator, blockIdx.y * gridDim.x + blockIdx.x);

@@ -563,11 +563,28 @@ extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const
             hipLaunchKernelGGL((generator_ws_kernel<4, 16>), dim3((N + 127) / 128, 1), dim3(256), GW_STAGES * 16 * 1024 + GW4_LDS_PAD, (hipStream_t)stream, a);
             return rac_launch_status("rac_generator_fwd");
         }
-        // narrow outputs (the 2189 features of the sampling Linears, not the generator's 65536): cut the rows into chunks so
-        // that feature blocks x chunks covers the CUs; every chunk re-reads its 256 weight rows (L2) for at least 32 rows of
-        // work.  One workgroup per CU (128 KB of LDS), so at most 256 workgroups: a 257th would wait for a whole round.
-        // (Measured at N = 2189, M = 900: 135 workgroups 14.8 us, 261 workgroups 20.5 us; an XCD-major item order that keeps a
-        //  feature block's chunks on one L2 changed nothing -- the weights' trip across the fabric is not what bounds it.)
+        // narrow outputs (the 2189 features of the sampling Linears, not the generator's 65536): the rows are cut into chunks so that
+        // feature blocks x chunks covers the CUs; every chunk re-reads its weight rows (L2) for a few row stages of work, so the
+        // weight prologue is most of a workgroup's life.  Round 5: the FOUR-wave shape here (128 features = 128 KB of weights per
+        // workgroup instead of 256 KB, 16-row stages, two workgroups per CU; about 512 workgroups): 15.6 -> 13.8 us at N = 2189, M = 900
+        // (the same shape LOSES on the wide generator, 104-106 us against 88-90: there the stage loop is everything).
+#if !defined(GW_NARROW_WAVES) || GW_NARROW_WAVES == 4
+        if (N < 128 * 128) {
+            const int fb = (N + 127) / 128;
+            int ch = fb >= 256 ? 1 : 512 / fb;
+            const int maxc = (M + 15) / 16;
+            ch = ch > maxc ? maxc : ch;
+            a.rows_per_wg = ((M + ch - 1) / ch + 15) / 16 * 16;
+            ch = (M + a.rows_per_wg - 1) / a.rows_per_wg;
+            if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_GENERATOR4, reinterpret_cast<const void *>(generator_ws_kernel<4, 16>), GW_STAGES * 16 * 1024 + GW4_LDS_PAD))
+                return rc_attr;
+            hipLaunchKernelGGL((generator_ws_kernel<4, 16>), dim3(fb, ch), dim3(256), GW_STAGES * 16 * 1024 + GW4_LDS_PAD, (hipStream_t)stream, a);
+            return rac_launch_status("rac_generator_fwd");
+        }
+#endif
+        // the eight-wave shape for narrow outputs (rounds 2-4; A/B builds with -DGW_NARROW_WAVES=8): one workgroup per CU (128 KB of
+        // LDS), so at most 256 workgroups: a 257th would wait for a whole round.  (Measured at N = 2189, M = 900: 135 workgroups
+        // 14.8 us, 261 workgroups 20.5 us; an XCD-major item order that keeps a feature block's chunks on one L2 changed nothing.)
         constexpr int ROWS = 32;
         const int fblocks = (N + 255) / 256;
         int chunks = fblocks >= 128 ? 1 : 256 / fblocks;

@@ -566,15 +566,18 @@ extern "C" int rac_generator_fwd(const void *x_image, const void *w_image, const
         // narrow outputs (the 2189 features of the sampling Linears, not the generator's 65536): the rows are cut into chunks so that
         // feature blocks x chunks covers the CUs; every chunk re-reads its weight rows (L2) for a few row stages of work, so the
         // weight prologue is most of a workgroup's life.  Round 5: the FOUR-wave shape here (128 features = 128 KB of weights per
-        // workgroup instead of 256 KB, 16-row stages, two workgroups per CU; about 512 workgroups): 15.6 -> 13.8 us at N = 2189, M = 900
+        // workgroup instead of 256 KB, 16-row stages; about 256 workgroups): 15.6 -> 12.3 us at N = 2189, M = 900
         // (the same shape LOSES on the wide generator, 104-106 us against 88-90: there the stage loop is everything).
 #if !defined(GW_NARROW_WAVES) || GW_NARROW_WAVES == 4
         if (N < 128 * 128) {
             const int fb = (N + 127) / 128;
-            int ch = fb >= 256 ? 1 : 512 / fb;
+            int ch = fb >= 256 ? 1 : 256 / fb;      // about one workgroup per CU (rows per workgroup 32 / 48 / 64 / 80 / 112: 15.7 / 13.9 / 12.9 / 12.3 / 12.7 us)
             const int maxc = (M + 15) / 16;
             ch = ch > maxc ? maxc : ch;
             a.rows_per_wg = ((M + ch - 1) / ch + 15) / 16 * 16;
+#ifdef GW_NARROW_ROWS
+            a.rows_per_wg = GW_NARROW_ROWS;      /* A/B builds */
+#endif
             ch = (M + a.rows_per_wg - 1) / a.rows_per_wg;
             if (const int rc_attr = rac_set_dynamic_lds_once(RAC_ATTR_GENERATOR4, reinterpret_cast<const void *>(generator_ws_kernel<4, 16>), GW_STAGES * 16 * 1024 + GW4_LDS_PAD))
                 return rc_attr;
